@@ -1,0 +1,383 @@
+"""TEST INFRASTRUCTURE ONLY - CPU oracle for the DiG diffusion-guidance hot path.
+
+This file is the *checker*: a functional, fp32, CPU restatement of what the
+reference computes on the path SURVEY.md section 8 lists.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it; the product (``dig_amd``) never does and fails loudly when its HIP
+library is missing.
+
+Pinning: every function here is checked against the reference itself, imported
+in the build container by ``oracle/gen_golden.py`` (max-abs deltas recorded in
+``tests/golden/MANIFEST.json``), and against the committed golden vectors under
+``tests/golden/`` (which travel to the GPU box; the reference does not).
+
+All tensors are NCHW fp32 torch CPU tensors; weights are a flat ``state_dict``
+mapping with the reference's key names (``GaussianDiffusion.state_dict()`` /
+``MCTformerV2_DiG.state_dict()``).  Citations are ``file:line`` into
+``/root/reference``; ``ddp.py`` abbreviates
+``denoising_diffusion_pytorch/denoising_diffusion_pytorch.py``.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+# --------------------------------------------------------------------------------------
+# schedule  (ddp.py:478-491 sigmoid schedule; ddp.py:534-601 buffers)
+# --------------------------------------------------------------------------------------
+def sigmoid_betas(timesteps, start=-3.0, end=3.0, tau=1.0):
+    """fp64 sigmoid beta schedule, ddp.py:478-491."""
+    t = torch.linspace(0, timesteps, timesteps + 1, dtype=torch.float64) / timesteps
+    v0 = torch.tensor(start / tau).sigmoid()  # fp32 scalars, as in the reference
+    v1 = torch.tensor(end / tau).sigmoid()
+    ac = (-((t * (end - start) + start) / tau).sigmoid() + v1) / (v1 - v0)
+    ac = ac / ac[0]
+    betas = 1 - ac[1:] / ac[:-1]
+    return betas.clamp(0, 0.999)
+
+
+def schedule_buffers(timesteps=1000):
+    """The 13 fp32 buffers GaussianDiffusion registers for objective='pred_v' (ddp.py:555-601)."""
+    b = sigmoid_betas(timesteps)
+    a = 1.0 - b
+    ac = torch.cumprod(a, 0)
+    acp = torch.cat([torch.ones(1, dtype=torch.float64), ac[:-1]])
+    pv = b * (1.0 - acp) / (1.0 - ac)
+    snr = ac / (1 - ac)
+    out = {
+        "betas": b, "alphas_cumprod": ac, "alphas_cumprod_prev": acp,
+        "sqrt_alphas_cumprod": ac.sqrt(),
+        "sqrt_one_minus_alphas_cumprod": (1.0 - ac).sqrt(),
+        "log_one_minus_alphas_cumprod": (1.0 - ac).log(),
+        "sqrt_recip_alphas_cumprod": (1.0 / ac).sqrt(),
+        "sqrt_recipm1_alphas_cumprod": (1.0 / ac - 1).sqrt(),
+        "posterior_variance": pv,
+        "posterior_log_variance_clipped": pv.clamp(min=1e-20).log(),
+        "posterior_mean_coef1": b * acp.sqrt() / (1.0 - ac),
+        "posterior_mean_coef2": (1.0 - acp) * a.sqrt() / (1.0 - ac),
+        "loss_weight": snr / (snr + 1),
+    }
+    return {k: v.to(torch.float32) for k, v in out.items()}
+
+
+def _gather(table, t, ndim):
+    """extract(), ddp.py:452-455."""
+    return table.gather(-1, t).reshape(t.shape[0], *((1,) * (ndim - 1)))
+
+
+def q_sample(sd, x0, t, noise):
+    """ddp.py:853-860."""
+    return (_gather(sd["sqrt_alphas_cumprod"], t, x0.dim()) * x0
+            + _gather(sd["sqrt_one_minus_alphas_cumprod"], t, x0.dim()) * noise)
+
+
+def predict_start_from_v(sd, x_t, t, v):
+    """ddp.py:630-634."""
+    return (_gather(sd["sqrt_alphas_cumprod"], t, x_t.dim()) * x_t
+            - _gather(sd["sqrt_one_minus_alphas_cumprod"], t, x_t.dim()) * v)
+
+
+# --------------------------------------------------------------------------------------
+# U-Net pieces
+# --------------------------------------------------------------------------------------
+def _sub(sd, prefix):
+    n = len(prefix)
+    return {k[n:]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+def time_embedding(w, t, dim):
+    """SinusoidalPosEmb + time_mlp, ddp.py:118-130,316-321.  `w` = sub-dict under 'time_mlp.'."""
+    half = dim // 2
+    freq = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1)))
+    ang = t.to(torch.float32)[:, None] * freq[None, :]
+    e = torch.cat([ang.sin(), ang.cos()], dim=-1)
+    e = F.linear(e, w["1.weight"], w["1.bias"])
+    e = F.gelu(e)  # exact erf GELU
+    return F.linear(e, w["3.weight"], w["3.bias"])
+
+
+def rms_norm(x, g):
+    """RMSNorm, ddp.py:108-114: L2-normalise over C (eps 1e-12) * g * sqrt(C)."""
+    n = x.pow(2).sum(1, keepdim=True).sqrt().clamp_min(1e-12)
+    return x / n * g * (x.shape[1] ** 0.5)
+
+
+def conv_gn_act(w, x, groups, scale_shift=None):
+    """Block, ddp.py:151-167."""
+    x = F.conv2d(x, w["proj.weight"], w["proj.bias"], padding=1)
+    x = F.group_norm(x, groups, w["norm.weight"], w["norm.bias"], eps=1e-5)
+    if scale_shift is not None:
+        sc, sh = scale_shift
+        x = x * (sc + 1) + sh
+    return F.silu(x)
+
+
+def resnet_block(w, x, temb, groups=8):
+    """ResnetBlock, ddp.py:169-194."""
+    ss = None
+    if "mlp.1.weight" in w and temb is not None:
+        e = F.linear(F.silu(temb), w["mlp.1.weight"], w["mlp.1.bias"])[:, :, None, None]
+        ss = e.chunk(2, dim=1)
+    h = conv_gn_act(_sub(w, "block1."), x, groups, ss)
+    h = conv_gn_act(_sub(w, "block2."), h, groups)
+    res = F.conv2d(x, w["res_conv.weight"], w["res_conv.bias"]) if "res_conv.weight" in w else x
+    return h + res
+
+
+def linear_attention(w, x, heads=4, dim_head=32):
+    """LinearAttention, ddp.py:196-233 (residual added by the caller)."""
+    b, c, hh, ww = x.shape
+    n = hh * ww
+    xn = rms_norm(x, w["norm.g"])
+    qkv = F.conv2d(xn, w["to_qkv.weight"]).reshape(b, 3, heads, dim_head, n)
+    q, k, v = qkv[:, 0], qkv[:, 1], qkv[:, 2]
+    q = q.softmax(dim=-2) * dim_head ** -0.5
+    k = k.softmax(dim=-1)
+    ctx = torch.einsum("bhdn,bhen->bhde", k, v)
+    out = torch.einsum("bhde,bhdn->bhen", ctx, q).reshape(b, heads * dim_head, hh, ww)
+    out = F.conv2d(out, w["to_out.0.weight"], w["to_out.0.bias"])
+    return rms_norm(out, w["to_out.1.g"])
+
+
+def attend(q, k, v):
+    """Attend.forward math path, attend.py:98-113 (== SDPA path, attend.py:65-82, to 2.4e-6)."""
+    sim = torch.einsum("bhid,bhjd->bhij", q, k) * q.shape[-1] ** -0.5
+    return torch.einsum("bhij,bhjd->bhid", sim.softmax(dim=-1), v)
+
+
+def full_attention(w, x, heads=4, dim_head=32):
+    """Attention, ddp.py:235-264."""
+    b, c, hh, ww = x.shape
+    n = hh * ww
+    xn = rms_norm(x, w["norm.g"])
+    qkv = F.conv2d(xn, w["to_qkv.weight"]).reshape(b, 3, heads, dim_head, n)
+    q, k, v = (qkv[:, i].transpose(-1, -2) for i in range(3))  # b h n d
+    o = attend(q, k, v)  # b h n d
+    o = o.transpose(-1, -2).reshape(b, heads * dim_head, hh, ww)
+    return F.conv2d(o, w["to_out.weight"], w["to_out.bias"])
+
+
+def downsample(w, x):
+    """Downsample, ddp.py:102-106: 'b c (h p1) (w p2) -> b (c p1 p2) h w' then conv1x1."""
+    return F.conv2d(F.pixel_unshuffle(x, 2), w["1.weight"], w["1.bias"])
+
+
+def upsample(w, x):
+    """Upsample, ddp.py:90-94: nearest x2 then conv3x3."""
+    return F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w["1.weight"], w["1.bias"], padding=1)
+
+
+def unet_structure(sd):
+    """Derive (dim, n_stages, full_attn flags) from the key set, so that the oracle follows
+    whatever Unet(...) configuration produced the state dict (ddp.py:289-373)."""
+    dim = sd["init_conv.weight"].shape[0]
+    n = 0
+    while f"downs.{n}.0.block1.proj.weight" in sd:
+        n += 1
+    full = [f"downs.{i}.2.to_out.weight" in sd for i in range(n)]
+    return dim, n, full
+
+
+def unet_forward(sd, x, t, groups=8, heads=4, dim_head=32, collect=None):
+    """Unet.forward eval branch, ddp.py:379-448.  `sd` = Unet state dict (no 'model.' prefix).
+    Returns (pred [B,3,H,W], [5 guidance maps at H/16 x W/16]).  `collect`, if a dict, receives
+    named intermediates for layer-by-layer debugging of the HIP path."""
+    dim, n_stage, full = unet_structure(sd)
+    H, W = x.shape[-2:]
+    assert H % 2 ** (n_stage - 1) == 0 and W % 2 ** (n_stage - 1) == 0  # ddp.py:380
+
+    def keep(name, val):
+        if collect is not None:
+            collect[name] = val
+        return val
+
+    x = F.conv2d(x, sd["init_conv.weight"], sd["init_conv.bias"], padding=3)
+    keep("init_conv", x)
+    r = x
+    temb = keep("temb", time_embedding(_sub(sd, "time_mlp."), t, dim))
+    skips, feats = [], []
+    for i in range(n_stage):
+        p = f"downs.{i}."
+        x = resnet_block(_sub(sd, p + "0."), x, temb, groups)
+        skips.append(x)
+        x = resnet_block(_sub(sd, p + "1."), x, temb, groups)
+        att = full_attention if full[i] else linear_attention
+        x = att(_sub(sd, p + "2."), x, heads, dim_head) + x
+        skips.append(x)
+        keep(p + "attn", x)
+        if i < n_stage - 1:
+            x = downsample(_sub(sd, p + "3."), x)
+        else:
+            x = F.conv2d(x, sd[p + "3.weight"], sd[p + "3.bias"], padding=1)
+        keep(p + "out", x)
+    x = resnet_block(_sub(sd, "mid_block1."), x, temb, groups)
+    x = full_attention(_sub(sd, "mid_attn."), x, heads, dim_head) + x
+    x = resnet_block(_sub(sd, "mid_block2."), x, temb, groups)
+    keep("mid", x)
+    size = (H // 16, W // 16)
+    feats.append(F.interpolate(x, size=size, mode="bilinear", align_corners=True))  # ddp.py:418
+    for j in range(n_stage):
+        i = n_stage - 1 - j  # mirrors reversed(full_attn), ddp.py:357
+        p = f"ups.{j}."
+        x = resnet_block(_sub(sd, p + "0."), torch.cat([x, skips.pop()], 1), temb, groups)
+        x = resnet_block(_sub(sd, p + "1."), torch.cat([x, skips.pop()], 1), temb, groups)
+        att = full_attention if full[i] else linear_attention
+        x = att(_sub(sd, p + "2."), x, heads, dim_head) + x
+        keep(p + "attn", x)
+        if j < n_stage - 1:
+            x = upsample(_sub(sd, p + "3."), x)
+        else:
+            x = F.conv2d(x, sd[p + "3.weight"], sd[p + "3.bias"], padding=1)
+        keep(p + "out", x)
+        feats.append(F.interpolate(x, size=size, mode="bilinear", align_corners=True))  # ddp.py:434
+    x = resnet_block(_sub(sd, "final_res_block."), torch.cat([x, r], 1), temb, groups)
+    return F.conv2d(x, sd["final_conv.weight"], sd["final_conv.bias"]), feats
+
+
+def p_losses_eval(sd, x_start, t, noise):
+    """GaussianDiffusion.p_losses eval branch, ddp.py:862-913 -> (x_t, model_out, feat_out).
+    `sd` = GaussianDiffusion state dict (schedule buffers + 'model.*')."""
+    x_t = q_sample(sd, x_start, t, noise)
+    v, feats = unet_forward(_sub(sd, "model."), x_t, t)
+    return x_t, v, feats
+
+
+# --------------------------------------------------------------------------------------
+# guidance-extraction glue  (models/model_ECCV24_DiG.py:286-316, 499-519)
+# --------------------------------------------------------------------------------------
+def denorm_for_diff(img):
+    """model.py:499-508 then diffusion.normalize (ddp.py:82-83)."""
+    m = torch.tensor(IMAGENET_MEAN).reshape(1, 3, 1, 1)
+    s = torch.tensor(IMAGENET_STD).reshape(1, 3, 1, 1)
+    return (img * s + m) * 2 - 1
+
+
+def norm_for_cls(img01):
+    """model.py:510-519."""
+    m = torch.tensor(IMAGENET_MEAN).reshape(1, 3, 1, 1)
+    s = torch.tensor(IMAGENET_STD).reshape(1, 3, 1, 1)
+    return (img01 - m) / s
+
+
+def guidance_maps(sd, img, noises, t_list=(0, 1, 2, 3, 4, 100), sfi=100):
+    """model.py:286-316.  `img` ImageNet-normalised [B,3,H,W]; `noises[j]` is the explicit noise
+    for t_list[j] (the reference draws it on device, ddp.py:865).  Returns
+    (list of len(t_list)-1 tensors [B,1024,H/16,W/16], img_diff [B,3,H,W])."""
+    x0 = denorm_for_diff(img)
+    out, img_diff = [], None
+    for j, nz in zip(t_list, noises):
+        t = torch.full((img.shape[0],), j, dtype=torch.long)
+        x_t, v, feats = p_losses_eval(sd, x0, t, nz)
+        if j == sfi:
+            img_diff = norm_for_cls((predict_start_from_v(sd, x_t, t, v) + 1) * 0.5)
+        else:
+            out.append(torch.cat(feats, dim=1))
+    return out, img_diff
+
+
+# --------------------------------------------------------------------------------------
+# MCTformer class-token attention -> CAM  (networks/mctformer.py, networks/vision_transformer.py)
+# --------------------------------------------------------------------------------------
+def vit_pos_embed(sd, num_classes, H, W, patch=16):
+    """interpolate_pos_encoding, mctformer.py:196-217 (note the reference's w/h naming:
+    its `w` is x.shape[2] = image height)."""
+    pe = sd["pos_embed"]
+    N = pe.shape[1] - num_classes
+    npatch = (H // patch) * (W // patch)
+    if npatch == N and H == W:
+        return pe
+    g = int(math.sqrt(N))
+    w0, h0 = H // patch + 0.1, W // patch + 0.1
+    pp = pe[:, num_classes:].reshape(1, g, g, -1).permute(0, 3, 1, 2)
+    pp = F.interpolate(pp, scale_factor=(w0 / math.sqrt(N), h0 / math.sqrt(N)), mode="bicubic")
+    assert int(w0) == pp.shape[-2] and int(h0) == pp.shape[-1]
+    pp = pp.permute(0, 2, 3, 1).reshape(1, -1, pe.shape[-1])
+    return torch.cat([pe[:, :num_classes], pp], dim=1)
+
+
+def vit_block(w, x, heads):
+    """Block + Attention + Mlp, vision_transformer.py:54-103,177-196.  Returns (x, probs)."""
+    B, N, D = x.shape
+    y = F.layer_norm(x, (D,), w["norm1.weight"], w["norm1.bias"], eps=1e-6)
+    qkv = F.linear(y, w["attn.qkv.weight"], w["attn.qkv.bias"]).reshape(B, N, 3, heads, D // heads)
+    q, k, v = qkv.permute(2, 0, 3, 1, 4)
+    p = ((q @ k.transpose(-2, -1)) * (D // heads) ** -0.5).softmax(dim=-1)
+    o = (p @ v).transpose(1, 2).reshape(B, N, D)
+    x = x + F.linear(o, w["attn.proj.weight"], w["attn.proj.bias"])
+    y = F.layer_norm(x, (D,), w["norm2.weight"], w["norm2.bias"], eps=1e-6)
+    y = F.linear(F.gelu(F.linear(y, w["mlp.fc1.weight"], w["mlp.fc1.bias"])), w["mlp.fc2.weight"], w["mlp.fc2.bias"])
+    return x + y, p
+
+
+def mctformer_cam(sd, img, n_layers=12, heads=6, patch=16, collect=None):
+    """MCTformerV2_DiG.forward(x, return_att=True) -> rcams, mctformer.py:227-263,293-321,347-348.
+    Also returns the intermediates the product exposes (mtatt, patch_attn, relu(head))."""
+    B, _, H, W = img.shape
+    C = sd["cls_token"].shape[1]
+    D = sd["cls_token"].shape[2]
+    x = F.conv2d(img, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=patch)
+    hp, wp = x.shape[-2:]
+    x = x.flatten(2).transpose(1, 2)
+    x = torch.cat([sd["cls_token"].expand(B, -1, -1), x], dim=1) + vit_pos_embed(sd, C, H, W, patch)
+    depth = 0
+    while f"blocks.{depth}.norm1.weight" in sd:
+        depth += 1
+    probs = []
+    for i in range(depth):
+        x, p = vit_block(_sub(sd, f"blocks.{i}."), x, heads)
+        probs.append(p.mean(dim=1))  # head mean, mctformer.py:303
+    if collect is not None:
+        collect["tokens"] = x
+    # no final self.norm in the DiG subclass (mctformer.py:242-250)
+    xp = x[:, C:].reshape(B, hp, wp, D).permute(0, 3, 1, 2).contiguous()
+    head = F.conv2d(xp, sd["head.weight"], sd["head.bias"], padding=1)
+    fmap = F.relu(head)
+    A = torch.stack(probs)  # depth,B,N,N
+    mtatt = A[-n_layers:].sum(0)[:, :C, C:].reshape(B, C, hp, wp)
+    cams = mtatt * fmap
+    patch_attn = A[:, :, C:, C:].sum(0)
+    rcams = torch.matmul(patch_attn.unsqueeze(1), cams.reshape(B, C, -1, 1)).reshape(B, C, hp, wp)
+    if collect is not None:
+        collect.update(mtatt=mtatt, patch_attn=patch_attn, fmap=fmap, head=head)
+    return rcams
+
+
+def max_norm(cam):
+    """model.py:572-578 == mctformer.py:219-225."""
+    N, C, H, W = cam.shape
+    cam = F.relu(cam)
+    mx = cam.reshape(N, C, -1).max(dim=-1)[0].reshape(N, C, 1, 1)
+    mn = cam.reshape(N, C, -1).min(dim=-1)[0].reshape(N, C, 1, 1)
+    return F.relu(cam - mn - 1e-5) / (mx - mn + 1e-5)
+
+
+def infer_multi_cam(sd, img, label, n_layers=12):
+    """model.py:468-477: flip-TTA CAM, bilinear upsample (align_corners=False) x label, max_norm.
+    Returns the normalised CAM [B,C,H,W] (the reference keeps [0] only because its batch is 1)."""
+    B, _, H, W = img.shape
+    C = label.shape[1]
+    cam = mctformer_cam(sd, img, n_layers)
+    cam = F.interpolate(cam, [H, W], mode="bilinear", align_corners=False) * label.reshape(B, C, 1, 1)
+    cf = mctformer_cam(sd, torch.flip(img, (3,)), n_layers)
+    cf = F.interpolate(cf, [H, W], mode="bilinear", align_corners=False) * label.reshape(B, C, 1, 1)
+    return max_norm(cam + torch.flip(cf, (3,)))
+
+
+def cam_dict_from(norm_cam, label):
+    """model.py:479-483: keep channels whose label > 1e-5 (single image)."""
+    return {i: norm_cam[i].numpy() for i in range(label.shape[0]) if label[i] > 1e-5}
+
+
+def cam_argmax_labels(cam_dict, threshold, num_cls=21):
+    """evaluation.py:42-50: tensor[0]=threshold, tensor[k+1]=cam_dict[k], argmax -> uint8."""
+    h, w = next(iter(cam_dict.values())).shape
+    t = np.zeros((num_cls, h, w), np.float32)
+    for k, v in cam_dict.items():
+        t[k + 1] = v
+    t[0] = threshold
+    return np.argmax(t, axis=0).astype(np.uint8)

@@ -1,0 +1,126 @@
+"""CPU tier: the oracle (oracle/dig_oracle.py) against the golden vectors that
+oracle/gen_golden.py produced from the imported reference (tests/golden/MANIFEST.json records the
+oracle-vs-reference deltas at generation time).  Tolerance 2e-5 max-abs fp32 (observed <= 1.1e-5)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+import dig_oracle as O
+from dig_amd import synth
+from dig_amd.diffusion import GaussianDiffusion, Unet
+from dig_amd.mctformer import create_model
+
+TOL = 2e-5
+torch.set_grad_enabled(False)
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def unet_sd(dim, image_size):
+    """Synthetic GaussianDiffusion state dict built from the PRODUCT's module tree (which must have
+    the reference's keys) - so this also checks state-dict compatibility."""
+    u = Unet(dim=dim, dim_mults=(1, 2, 4, 8), flash_attn=True)
+    synth.fill_state_dict(u, seed=0)
+    gd = GaussianDiffusion(u, image_size=image_size, timesteps=1000, sampling_timesteps=150)
+    return {k: v.clone() for k, v in gd.state_dict().items()}
+
+
+def test_manifest_pins_oracle():
+    with open(os.path.join(os.path.dirname(__file__), "golden", "MANIFEST.json")) as f:
+        man = json.load(f)
+    for case, d in man["cases"].items():
+        for k, v in d.items():
+            if k == "argmax_flips":
+                assert v == 0
+            else:
+                assert v <= 1.5e-5, (case, k, v)
+
+
+def test_schedule(golden):
+    g = golden("schedule")
+    mine = O.schedule_buffers(1000)
+    assert sorted(g.files) == sorted(mine)
+    for k in g.files:
+        assert np.array_equal(g[k], mine[k].numpy()), k
+    assert abs(float(g["sqrt_alphas_cumprod"][100]) - 0.97979611) < 1e-7
+    assert abs(float(g["sqrt_one_minus_alphas_cumprod"][100]) - 0.19999881) < 1e-7
+
+
+def _check_unet(golden, name, dim, H, W, B):
+    g = golden(name)
+    sd = unet_sd(dim, H)
+    x0 = synth.synth_images(B, H, W, 1234)
+    nz = synth.synth_noise(B, H, W, 1235)
+    t = T(g["t"])
+    x_t, v, feats = O.p_losses_eval(sd, x0, t, nz)
+    assert (x_t - T(g["x_t"])).abs().max() <= TOL
+    assert (v - T(g["v"])).abs().max() <= TOL
+    for i, f in enumerate(feats):
+        assert f.shape == g[f"feat{i}"].shape
+        assert (f - T(g[f"feat{i}"])).abs().max() <= TOL
+
+
+def test_unet_tiny(golden):
+    _check_unet(golden, "unet_tiny32", 16, 32, 32, 2)
+
+
+def test_unet_rect(golden):
+    _check_unet(golden, "unet_rect_48x32", 16, 48, 32, 1)
+
+
+def test_unet128_config1(golden):
+    _check_unet(golden, "unet128_t100", 64, 128, 128, 1)
+
+
+def test_guidance_loop(golden):
+    g = golden("guidance64")
+    sd = unet_sd(64, 64)
+    img = synth.synth_imagenet_images(1, 64, 64)
+    tl = [0, 1, 2, 3, 4, 100]
+    noises = [synth.synth_noise(1, 64, 64, seed=1235 + 1000 * j) for j in range(len(tl))]
+    maps, img_diff = O.guidance_maps(sd, img, noises, tl)
+    assert len(maps) == 5 and maps[0].shape == (1, 1024, 4, 4)
+    for j, m in enumerate(maps):
+        assert (m - T(g[f"map_t{j}"])).abs().max() <= TOL
+    assert (img_diff - T(g["img_diff"])).abs().max() <= TOL
+
+
+def _cam_sd(C):
+    m = create_model("deit_small_MCTformerV2_DiG", pretrained=False, num_classes=C, lfca=False)
+    synth.fill_state_dict(m, seed=0, skip_prefixes=("LFCA", "diff_head_p", "norm."))
+    return {k: v.clone() for k, v in m.state_dict().items()}
+
+
+def _check_cam(golden, name, C, H, W):
+    g = golden(name)
+    sd = _cam_sd(C)
+    img = synth.synth_imagenet_images(1, H, W)
+    label = synth.synth_labels(1, C)
+    assert np.array_equal(label.numpy(), g["label"])
+    col = {}
+    rc = O.mctformer_cam(sd, img, 12, collect=col)
+    assert (rc - T(g["rcams"])).abs().max() <= TOL
+    assert (col["mtatt"] - T(g["mtatt"])).abs().max() <= TOL
+    norm = O.infer_multi_cam(sd, img, label, 12)
+    cd = O.cam_dict_from(norm[0], label[0])
+    for thr in (0.35, 0.45):
+        lab = O.cam_argmax_labels(cd, thr, C + 1)
+        assert np.array_equal(lab, g[f"labels_b0_t{int(thr * 100)}"])  # bit-exact labels
+    for i, a in cd.items():
+        assert np.abs(a - g[f"normcam_b0_c{i}"].astype(np.float32)).max() <= 1e-3  # fp16-stored fixture
+
+
+def test_cam_224_c20(golden):
+    _check_cam(golden, "cam224_c20", 20, 224, 224)
+
+
+def test_cam_nonsquare(golden):
+    _check_cam(golden, "cam160x208_c20", 20, 160, 208)
+
+
+def test_cam_c80(golden):
+    _check_cam(golden, "cam224_c80", 80, 224, 224)
