@@ -1,0 +1,119 @@
+"""ctypes binding of libdig_hip.so (the C-ABI boundary declared in include/dig_hip.h).
+
+The argument structs are generated from the header text itself, so the Python mirror cannot drift from
+the C declarations.  There is NO fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "dig_hip.h")
+LIB_PATH = os.path.join(_HERE, "csrc", "libdig_hip.so")
+
+DIG_BF16, DIG_F32 = 0, 1
+
+_SCALARS = {"int": ctypes.c_int, "float": ctypes.c_float, "long long": ctypes.c_longlong}
+
+
+def _parse_header(text):
+    """-> (structs {name: [(field, ctype)]}, functions [name])"""
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    structs = {}
+    for body, name in re.findall(r"typedef\s+struct\s*\{(.*?)\}\s*(\w+)\s*;", text, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            if "*" in decl:  # pointer field(s): "const void* a" (one per declaration in this header)
+                fname = decl.rsplit("*", 1)[1].strip()
+                fields.append((fname, ctypes.c_void_p))
+                continue
+            for base in ("long long", "int", "float"):
+                if decl.startswith(base + " "):
+                    for item in decl[len(base):].split(","):
+                        item = item.strip()
+                        m = re.match(r"(\w+)\[(\d+)\]$", item)
+                        if m:
+                            fields.append((m.group(1), _SCALARS[base] * int(m.group(2))))
+                        else:
+                            fields.append((item, _SCALARS[base]))
+                    break
+            else:
+                raise RuntimeError(f"dig_hip.h: cannot parse field declaration {decl!r}")
+        structs[name] = fields
+    funcs = re.findall(r"^\s*(?:int|const char\*)\s+(dig_\w+)\s*\(", text, flags=re.M)
+    return structs, funcs
+
+
+with open(HEADER) as _f:
+    _STRUCT_FIELDS, FUNCTIONS = _parse_header(_f.read())
+
+STRUCTS = {}
+for _name, _fields in _STRUCT_FIELDS.items():
+    STRUCTS[_name] = type(_name, (ctypes.Structure,), {"_fields_": _fields})
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built - never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `make -C dig_amd/csrc` (or __graft_entry__.build()). "
+                "dig_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for fn in FUNCTIONS:
+            f = getattr(L, fn)  # AttributeError if a declared symbol is not exported
+            f.restype = ctypes.c_char_p if fn == "dig_last_error" else ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    return x.data_ptr()  # torch.Tensor
+
+
+def call(fn, stream=None, **kw):
+    """Call `int dig_<fn>(const dig_<fn>_args*, void* stream)` with keyword fields; tensors become pointers.
+    `stream` defaults to torch's current HIP stream.  Raises RuntimeError on a non-zero return."""
+    import torch
+
+    L = lib()
+    sname = {"gemm_nt": "dig_gemm_args", "qsample_stem": "dig_stem_args", "bilinear_ac_concat": "dig_bilinear_ac_args",
+             "nchw_f32_to_nhwc": "dig_layout_args", "nhwc_to_nchw_f32": "dig_layout_args"}.get(fn, f"dig_{fn}_args")
+    S = STRUCTS[sname]
+    args = S()
+    valid = {f for f, _ in S._fields_}
+    for k, v in kw.items():
+        if k not in valid:
+            raise TypeError(f"{sname} has no field {k!r}")
+        ftype = dict(S._fields_)[k]
+        if ftype is ctypes.c_void_p:
+            setattr(args, k, _ptr(v))
+        elif hasattr(ftype, "_length_"):
+            setattr(args, k, ftype(*v))
+        else:
+            setattr(args, k, v)
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    rc = getattr(L, "dig_" + fn)(ctypes.byref(args), ctypes.c_void_p(stream))
+    if rc != 0:
+        raise RuntimeError(f"dig_{fn} failed ({rc}): {L.dig_last_error().decode()}")
+
+
+def dtype_code(torch_dtype):
+    import torch
+
+    if torch_dtype == torch.bfloat16:
+        return DIG_BF16
+    if torch_dtype == torch.float32:
+        return DIG_F32
+    raise ValueError(f"unsupported dtype {torch_dtype}; the HIP path stores activations as bfloat16 or float32")

@@ -1,0 +1,282 @@
+// conv3x3 (pad 1) as an implicit GEMM on MFMA, NHWC, gfx950.
+//
+// One 256-thread block (4 waves) computes a 16x16-pixel tile x BN output channels.  Per K-chunk of KC
+// input channels it stages ONE 18x18 halo tile of the input in LDS (each input element is fetched once and
+// reused by all 9 taps - no im2col traffic) plus the [9][BN][KC] weight slab, then runs 9*KC/16 MFMA steps
+// whose A operands are plain shifted reads of the halo tile.  The loader can (a) read a channel concat of two
+// tensors, (b) read the input through nearest-x2 addressing and (c) apply the previous Block's
+// GroupNorm-apply + SiLU on the fly, so none of those ever makes its own HBM pass.  The epilogue adds the
+// bias, writes the raw conv output and emits per-tile (sum, sumsq) partials for the next GroupNorm.
+//
+// LDS pixel stride is KC+8 elements and the halo row stride is padded to a multiple of 256 B so that the
+// 16-lane groups of ds_read_b128 hit 16 distinct 16-B slots (conflict-free A and B fragment reads).
+#include "common.hpp"
+
+namespace {
+
+constexpr int TILE = 16;           // 16x16 output pixels per block
+constexpr int HALO = TILE + 2;     // 18
+constexpr int NTHREADS = 256;
+
+template <typename T, int KC> struct ConvCfg {
+    static constexpr int KCP = KC + 8;  // padded per-pixel channel stride (elements)
+    static constexpr int HROW = ((HALO * KCP * (int)sizeof(T) + 255) / 256) * 256 / (int)sizeof(T);
+    static constexpr int HALO_ELEMS = HALO * HROW;
+};
+
+template <typename T, int BN, int KC> constexpr size_t conv_lds_bytes() {
+    using C = ConvCfg<T, KC>;
+    size_t main = (size_t)(C::HALO_ELEMS + 9 * BN * C::KCP) * sizeof(T);
+    size_t epi = (size_t)(4 * 2 * BN * 2 + BN * 2) * sizeof(float);
+    return main > epi ? main : epi;
+}
+
+template <typename T> struct Params {
+    const T* in[2];
+    int C[2];
+    const float* aff0;
+    const T* w;
+    const float* bias;
+    T* out;
+    float* stats;
+    int B, H, W, Cout, groups, up2, tiles_x, tiles_y;
+};
+
+template <typename T, int BN, int KC>
+__global__ __launch_bounds__(NTHREADS) void conv3x3_kernel(Params<T> p) {
+    using C = ConvCfg<T, KC>;
+    constexpr int KCP = C::KCP, HROW = C::HROW;
+    constexpr int NR = BN / 32, MR = 2;
+    constexpr int V = KC / 8;  // 8-element vectors per pixel per chunk
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* halo = reinterpret_cast<T*>(smem_raw);
+    T* wl = halo + C::HALO_ELEMS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hf = lane >> 5;
+    const int tiles = p.tiles_x * p.tiles_y;
+    const int b = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int ty0 = (tile / p.tiles_x) * TILE, tx0 = (tile % p.tiles_x) * TILE;
+    const int n0 = blockIdx.y * BN;
+    const int Cin = p.C[0] + p.C[1];
+    const int Hs = p.up2 ? p.H >> 1 : p.H, Ws = p.up2 ? p.W >> 1 : p.W;  // source dims
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; i++)
+#pragma unroll
+        for (int j = 0; j < NR; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    const int c8 = tid % V;  // this thread's vector slot inside a chunk (constant: 256 % V == 0)
+    // One flat loop over the K-chunks of both concat pieces (a nested piece/chunk loop made hipcc shuttle an
+    // accumulator register through a VGPR copy at the inner loop's exit, read before the last MFMA had retired).
+    const int nch0 = (p.C[0] + KC - 1) / KC, nch1 = (p.C[1] + KC - 1) / KC;
+    for (int ci = 0; ci < nch0 + nch1; ci++) {
+        const int piece = ci >= nch0 ? 1 : 0;
+        const int cb = (ci - (piece ? nch0 : 0)) * KC;
+        const int Cp = p.C[piece];
+        const T* src = p.in[piece];
+        const int koff = piece ? p.C[0] : 0;
+        const bool pro = (piece == 0) && (p.aff0 != nullptr);
+        const int ch = cb + c8 * 8;
+        const bool chv = ch < Cp;
+        float pa[8], pb[8];
+        if (pro && chv) {
+            const float* af = p.aff0 + ((size_t)b * Cp + ch) * 2;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                pa[j] = af[2 * j];
+                pb[j] = af[2 * j + 1];
+            }
+        }
+        __syncthreads();  // previous chunk's MFMA reads are done
+        // ---- halo tile: 18*18 pixels x V vectors
+        for (int idx = tid; idx < HALO * HALO * V; idx += NTHREADS) {
+            const int pix = idx / V;
+            const int hy = pix / HALO, hx = pix - hy * HALO;
+            const int Y = ty0 + hy - 1, X = tx0 + hx - 1;
+            Frag<T> f;
+            const bool ok = chv && Y >= 0 && Y < p.H && X >= 0 && X < p.W;
+            if (ok) {
+                const int sy = p.up2 ? Y >> 1 : Y, sx = p.up2 ? X >> 1 : X;
+                frag_load<T>(f, src + (((size_t)b * Hs + sy) * Ws + sx) * Cp + ch);
+                if (pro) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) frag_set<T>(f, j, silu_f(pa[j] * frag_get<T>(f, j) + pb[j]));
+                }
+            } else {
+                frag_zero<T>(f);
+            }
+            frag_store<T>(f, halo + hy * HROW + hx * KCP + c8 * 8);
+        }
+        // ---- weight slab [9][BN][KC] <- w[n][tap][koff+cb+..]
+        for (int idx = tid; idx < 9 * BN * V; idx += NTHREADS) {
+            const int row = idx / V;  // tap*BN + n
+            const int tap = row / BN, n = row - tap * BN;
+            Frag<T> f;
+            if (chv && (n0 + n) < p.Cout)
+                frag_load<T>(f, p.w + ((size_t)(n0 + n) * 9 + tap) * Cin + koff + ch);
+            else
+                frag_zero<T>(f);
+            frag_store<T>(f, wl + row * KCP + c8 * 8);
+        }
+        __syncthreads();
+        // ---- 9 taps x KC/16 MFMA steps
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+            for (int kk = 0; kk < KC / 16; kk++) {
+                Frag<T> fa[MR], fb[NR];
+#pragma unroll
+                for (int mr = 0; mr < MR; mr++) {
+                    const int py = wave * 4 + mr * 2 + (r >> 4), px = r & 15;
+                    frag_load<T>(fa[mr], halo + (py + ky) * HROW + (px + kx) * KCP + kk * 16 + hf * 8);
+                }
+#pragma unroll
+                for (int nr = 0; nr < NR; nr++)
+                    frag_load<T>(fb[nr], wl + (tap * BN + nr * 32 + r) * KCP + kk * 16 + hf * 8);
+#pragma unroll
+                for (int mr = 0; mr < MR; mr++)
+#pragma unroll
+                    for (int nr = 0; nr < NR; nr++) mma16<T>(acc[mr][nr], fa[mr], fb[nr]);
+            }
+        }
+    }
+    // Let the last MFMA retire before anything reads the accumulators (16-pass MFMA -> VALU read needs 18 wait
+    // states; do not rely on the hazard recognizer across the loop exit), and fence LDS for the epilogue.
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+
+    // ---- epilogue: bias, store, GroupNorm partials
+    float cs[NR], css[NR];
+#pragma unroll
+    for (int nr = 0; nr < NR; nr++) {
+        const int n = n0 + nr * 32 + r;
+        const bool nv = n < p.Cout;
+        const float bias = nv ? p.bias[n] : 0.f;
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int mr = 0; mr < MR; mr++) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int row = acc_row(e, lane);  // 0..31 inside the M sub-tile
+                const int py = wave * 4 + mr * 2 + (row >> 4), px = row & 15;
+                const int Y = ty0 + py, X = tx0 + px;
+                if (nv && Y < p.H && X < p.W) {
+                    const float v = acc[mr][nr][e] + bias;
+                    p.out[(((size_t)b * p.H + Y) * p.W + X) * p.Cout + n] = from_f32<T>(v);
+                    s += v;
+                    ss += v * v;
+                }
+            }
+        }
+        cs[nr] = s;
+        css[nr] = ss;
+    }
+    if (p.stats != nullptr) {
+        float* st = reinterpret_cast<float*>(smem_raw);  // [wave][half][BN][2], then [BN][2]
+        float* col = st + 4 * 2 * BN * 2;
+#pragma unroll
+        for (int nr = 0; nr < NR; nr++) {
+            float* d = st + (((wave * 2 + hf) * BN) + nr * 32 + r) * 2;
+            d[0] = cs[nr];
+            d[1] = css[nr];
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float s = 0.f, ss = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {  // fixed order -> deterministic
+                s += st[(k * BN + tid) * 2];
+                ss += st[(k * BN + tid) * 2 + 1];
+            }
+            col[tid * 2] = s;
+            col[tid * 2 + 1] = ss;
+        }
+        __syncthreads();
+        const int cpg = p.Cout / p.groups;
+        const int gpt = BN / cpg;  // groups covered by this N tile (host guarantees cpg | BN)
+        if (tid < gpt) {
+            const int g = (n0 / cpg) + tid;
+            if (g < p.groups) {
+                float s = 0.f, ss = 0.f;
+                for (int c = 0; c < cpg; c++) {
+                    s += col[(tid * cpg + c) * 2];
+                    ss += col[(tid * cpg + c) * 2 + 1];
+                }
+                float* dst = p.stats + (((size_t)b * p.groups + g) * tiles + tile) * 2;
+                dst[0] = s;
+                dst[1] = ss;
+            }
+        }
+    }
+}
+
+template <typename T, int BN, int KC>
+int launch(const dig_conv3x3_args* a, hipStream_t stream) {
+    Params<T> p;
+    p.in[0] = (const T*)a->in0;
+    p.in[1] = (const T*)a->in1;
+    p.C[0] = a->C0;
+    p.C[1] = a->in1 ? a->C1 : 0;
+    p.aff0 = a->aff0;
+    p.w = (const T*)a->w;
+    p.bias = a->bias;
+    p.out = (T*)a->out;
+    p.stats = a->stats;
+    p.B = a->B; p.H = a->H; p.W = a->W; p.Cout = a->Cout; p.groups = a->groups; p.up2 = a->up2;
+    p.tiles_x = cdiv(a->W, TILE);
+    p.tiles_y = cdiv(a->H, TILE);
+    constexpr size_t lds = conv_lds_bytes<T, BN, KC>();
+    static bool attr_set[64] = {};  // per instantiation, per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel<T, BN, KC>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "conv3x3: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
+        attr_set[dev] = true;
+    }
+    dim3 grid(a->B * p.tiles_x * p.tiles_y, cdiv(a->Cout, BN));
+    hipLaunchKernelGGL((conv3x3_kernel<T, BN, KC>), grid, dim3(NTHREADS), lds, stream, p);
+    DIG_LAUNCH_CHECK("conv3x3");
+    return DIG_OK;
+}
+
+}  // namespace
+
+extern "C" int dig_conv3x3_tiles(int H, int W) { return cdiv(H, TILE) * cdiv(W, TILE); }
+
+extern "C" int dig_conv3x3(const dig_conv3x3_args* a, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DIG_CHECK(a && a->in0 && a->w && a->bias && a->out, DIG_EINVAL, "conv3x3: null pointer");
+    DIG_CHECK(a->B > 0 && a->H > 0 && a->W > 0 && a->Cout > 0, DIG_EINVAL, "conv3x3: bad shape B=%d H=%d W=%d Cout=%d", a->B, a->H, a->W, a->Cout);
+    DIG_CHECK(a->C0 > 0 && a->C0 % 8 == 0 && (a->in1 == nullptr || (a->C1 > 0 && a->C1 % 8 == 0)), DIG_EINVAL,
+              "conv3x3: channel counts must be positive multiples of 8 (C0=%d C1=%d)", a->C0, a->C1);
+    DIG_CHECK(!a->up2 || (a->H % 2 == 0 && a->W % 2 == 0), DIG_EINVAL, "conv3x3: up2 needs even H,W");
+    DIG_CHECK(((uintptr_t)a->in0 | (uintptr_t)a->in1 | (uintptr_t)a->w | (uintptr_t)a->out) % 16 == 0, DIG_EALIGN,
+              "conv3x3: pointers must be 16-byte aligned");
+    int BN = (a->Cout % 128 == 0) ? 128 : (a->Cout > 32 ? 64 : 32);
+    if (a->dtype == DIG_F32 && BN > 64) BN = 64;
+    if (a->stats) {
+        DIG_CHECK(a->groups > 0 && a->Cout % a->groups == 0, DIG_EINVAL, "conv3x3: Cout %% groups != 0");
+        const int cpg = a->Cout / a->groups;
+        DIG_CHECK(cpg <= BN && BN % cpg == 0 && a->Cout % cpg == 0, DIG_EINVAL,
+                  "conv3x3: GroupNorm group width %d does not tile the %d-channel block", cpg, BN);
+    }
+    if (a->dtype == DIG_BF16) {
+        if (BN == 128) return launch<bf16, 128, 16>(a, stream);
+        if (BN == 64) return launch<bf16, 64, 32>(a, stream);
+        return launch<bf16, 32, 32>(a, stream);
+    } else if (a->dtype == DIG_F32) {
+        if (BN >= 64) return launch<float, 64, 16>(a, stream);
+        return launch<float, 32, 16>(a, stream);
+    }
+    DIG_CHECK(false, DIG_EINVAL, "conv3x3: unknown dtype %d", a->dtype);
+}

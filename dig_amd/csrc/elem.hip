@@ -1,0 +1,400 @@
+// HBM-bound helper kernels of the U-Net path (gfx950): GroupNorm finalize / apply, RMSNorm, softmaxes,
+// schedule arithmetic, sinusoidal embedding, activations, bilinear(align_corners=True)+concat, layout converters.
+// All global accesses on NHWC tensors are 16-byte vectors (8 x bf16 / 2 x 4 x f32), coalesced along C.
+#include "common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm finalize: one 64-thread block per (image, group).  Partials are summed in a fixed order in
+// fp64 so the result is deterministic and free of E[x^2]-mean^2 cancellation at fp32.
+__global__ void gn_finalize_kernel(dig_gn_finalize_args a) {
+    const int b = blockIdx.x / a.groups, g = blockIdx.x % a.groups;
+    const int cpg = a.C / a.groups;
+    const float* st = a.stats + ((size_t)b * a.groups + g) * a.tiles * 2;
+    double s = 0.0, ss = 0.0;
+    for (int i = threadIdx.x; i < a.tiles; i += 64) {
+        s += (double)st[2 * i];
+        ss += (double)st[2 * i + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        ss += __shfl_xor(ss, o, 64);
+    }
+    const double n = (double)cpg * (double)a.hw;
+    const double mean = s / n;
+    double var = ss / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    const float meanf = (float)mean;
+    for (int i = threadIdx.x; i < cpg; i += 64) {
+        const int c = g * cpg + i;
+        float ga = a.gamma[c] * rstd;
+        float be = a.beta[c] - meanf * ga;
+        if (a.ss) {
+            const float* row = a.ss + (size_t)b * a.ss_ld + a.ss_off;
+            const float sc = row[c] + 1.0f, sh = row[a.C + c];
+            ga *= sc;
+            be = be * sc + sh;
+        }
+        float* d = a.aff + ((size_t)b * a.C + c) * 2;
+        d[0] = ga;
+        d[1] = be;
+    }
+}
+
+// out = silu(a*x+b) [+ res], 8 elements per thread-iteration
+template <typename T> __global__ void gn_silu_add_kernel(dig_gn_silu_add_args a) {
+    const int cv = a.C / 8;
+    const size_t per_img = (size_t)a.HW * cv, total = per_img * a.B;
+    const T* x = (const T*)a.x;
+    const T* res = (const T*)a.res;
+    T* out = (T*)a.out;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(v / per_img);
+        const int c = (int)(v % cv) * 8;
+        const float* af = a.aff + ((size_t)b * a.C + c) * 2;
+        Frag<T> f, r;
+        frag_load<T>(f, x + v * 8);
+        if (res) frag_load<T>(r, res + v * 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float y = silu_f(af[2 * j] * frag_get<T>(f, j) + af[2 * j + 1]);
+            if (res) y += frag_get<T>(r, j);
+            frag_set<T>(f, j, y);
+        }
+        frag_store<T>(f, out + v * 8);
+    }
+}
+
+// RMSNorm: G = lanes cooperating on one row (C/8 vectors per row handled as ceil(C/8/G) vectors per lane)
+template <typename T, int G> __global__ void rmsnorm_kernel(dig_rmsnorm_args a) {
+    const int cv = a.C / 8;
+    const int rows_per_block = blockDim.x / G;
+    const int sub = threadIdx.x % G;
+    const T* x = (const T*)a.x;
+    const T* res = (const T*)a.res;
+    T* out = (T*)a.out;
+    const float mult = sqrtf((float)a.C);
+    // all G lanes of a group share `row`, so a group enters/leaves the loop together and the shuffles below
+    // only ever exchange data between lanes that are active.
+    for (long long row = (long long)blockIdx.x * rows_per_block + threadIdx.x / G; row < a.rows;
+         row += (long long)gridDim.x * rows_per_block) {
+        float ssq = 0.f;
+        for (int v = sub; v < cv; v += G) {
+            Frag<T> f;
+            frag_load<T>(f, x + (size_t)row * a.C + v * 8);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float t = frag_get<T>(f, j);
+                ssq += t * t;
+            }
+        }
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) ssq += __shfl_xor(ssq, o, 64);
+        const float inv = mult / fmaxf(sqrtf(ssq), 1e-12f);
+        for (int v = sub; v < cv; v += G) {
+            Frag<T> f, r;
+            frag_load<T>(f, x + (size_t)row * a.C + v * 8);
+            if (res) frag_load<T>(r, res + (size_t)row * a.C + v * 8);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                float y = frag_get<T>(f, j) * inv * a.g[v * 8 + j];
+                if (res) y += frag_get<T>(r, j);
+                frag_set<T>(f, j, y);
+            }
+            frag_store<T>(f, out + (size_t)row * a.C + v * 8);
+        }
+    }
+}
+
+// softmax over contiguous rows; one block per row
+template <typename TI, typename TO> __global__ void row_softmax_kernel(const TI* in, TO* out, int n) {
+    __shared__ float red[32];
+    const TI* x = in + (size_t)blockIdx.x * n;
+    TO* y = out + (size_t)blockIdx.x * n;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, (float)x[i]);
+    m = block_max(m, red);
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += __expf((float)x[i] - m);
+    s = block_sum(s, red);
+    const float inv = 1.0f / s;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) y[i] = (TO)(__expf((float)x[i] - m) * inv);
+}
+
+// q softmax over each 32-channel head slice, times scale; one thread per (row, head)
+template <typename T> __global__ void group_softmax32_kernel(dig_group_softmax32_args a) {
+    T* q = (T*)a.q;
+    const long long total = a.rows * a.groups;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        T* p = q + i * 32;
+        Frag<T> f[4];
+        float m = -INFINITY;
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            frag_load<T>(f[v], p + v * 8);
+#pragma unroll
+            for (int j = 0; j < 8; j++) m = fmaxf(m, frag_get<T>(f[v], j));
+        }
+        float e[32], s = 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; v++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                e[v * 8 + j] = __expf(frag_get<T>(f[v], j) - m);
+                s += e[v * 8 + j];
+            }
+        const float inv = a.scale / s;
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) frag_set<T>(f[v], j, e[v * 8 + j] * inv);
+            frag_store<T>(f[v], p + v * 8);
+        }
+    }
+}
+
+template <typename T> __global__ void row_max_kernel(dig_row_max_args a) {
+    __shared__ float red[32];
+    const long long grp = blockIdx.x / a.group_rows, sub = blockIdx.x % a.group_rows;
+    const T* x = (const T*)a.in + grp * a.group_stride + sub * (long long)a.n;
+    float m = -INFINITY;
+    const int nv = a.n / 8;
+    for (int v = threadIdx.x; v < nv; v += blockDim.x) {
+        Frag<T> f;
+        frag_load<T>(f, x + v * 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) m = fmaxf(m, frag_get<T>(f, j));
+    }
+    m = block_max(m, red);
+    if (threadIdx.x == 0) a.out[blockIdx.x] = m;
+}
+
+// out = post_scale[c]*(ca[t[b]]*x + sign*cs[t[b]]*y) + post_shift[c]   (NCHW fp32)
+__global__ void sched_axpby_kernel(dig_sched_axpby_args a) {
+    const size_t total = (size_t)a.B * 3 * a.HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / ((size_t)3 * a.HW));
+        const int c = (int)((i / a.HW) % 3);
+        const long long t = a.t[b];
+        const float v = a.sqrt_ac[t] * a.x[i] + a.sign * a.sqrt_1mac[t] * a.y[i];
+        a.out[i] = a.post_scale[c] * v + a.post_shift[c];
+    }
+}
+
+template <typename T> __global__ void sinusoid_kernel(dig_sinusoid_args a) {
+    const int half = a.dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.B * a.dim) return;
+    const int b = i / a.dim, j = i % a.dim;
+    const int fi = j < half ? j : j - half;
+    // same op order as the reference: exp(arange * -(ln(1e4)/(half-1))) then t * freq (ddp.py:126-128)
+    const float freq = expf((float)fi * -(logf(10000.0f) / (float)(half - 1)));
+    const float ang = (float)a.t[b] * freq;
+    ((T*)a.out)[i] = from_f32<T>(j < half ? sinf(ang) : cosf(ang));
+}
+
+template <typename TI, typename TO> __global__ void act_kernel(const TI* in, TO* out, long long n, int act) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float x = (float)in[i];
+        out[i] = (TO)(act == 0 ? silu_f(x) : gelu_erf_f(x));
+    }
+}
+
+// bilinear align_corners=True from NHWC T to an NCHW fp32 slice; thread = (b, oy, ox, c), c fastest
+template <typename T> __global__ void bilinear_ac_kernel(dig_bilinear_ac_args a) {
+    const size_t total = (size_t)a.B * a.h * a.w * a.C;
+    const T* in = (const T*)a.in;
+    const float sy = a.h > 1 ? (float)(a.H - 1) / (float)(a.h - 1) : 0.f;
+    const float sx = a.w > 1 ? (float)(a.W - 1) / (float)(a.w - 1) : 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % a.C);
+        size_t rest = i / a.C;
+        const int ox = (int)(rest % a.w);
+        rest /= a.w;
+        const int oy = (int)(rest % a.h);
+        const int b = (int)(rest / a.h);
+        const float fy = sy * oy, fx = sx * ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < a.H - 1 ? 1 : 0), x1 = x0 + (x0 < a.W - 1 ? 1 : 0);
+        const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+        const T* base = in + (size_t)b * a.H * a.W * a.C + c;
+        const float p00 = to_f32<T>(base[((size_t)y0 * a.W + x0) * a.C]);
+        const float p01 = to_f32<T>(base[((size_t)y0 * a.W + x1) * a.C]);
+        const float p10 = to_f32<T>(base[((size_t)y1 * a.W + x0) * a.C]);
+        const float p11 = to_f32<T>(base[((size_t)y1 * a.W + x1) * a.C]);
+        a.out[(((size_t)b * a.Ctot + a.c_off + c) * a.h + oy) * a.w + ox] = hy * (hx * p00 + lx * p01) + ly * (hx * p10 + lx * p11);
+    }
+}
+
+template <typename T> __global__ void nchw_to_nhwc_kernel(const float* in, T* out, int B, int C, int HW) {
+    const size_t total = (size_t)B * C * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t rest = i / C;
+        const int pix = (int)(rest % HW);
+        const int b = (int)(rest / HW);
+        out[i] = from_f32<T>(in[((size_t)b * C + c) * HW + pix]);
+    }
+}
+template <typename T> __global__ void nhwc_to_nchw_kernel(const T* in, float* out, int B, int C, int HW) {
+    const size_t total = (size_t)B * C * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int pix = (int)(i % HW);
+        const size_t rest = i / HW;
+        const int c = (int)(rest % C);
+        const int b = (int)(rest / C);
+        out[i] = to_f32<T>(in[((size_t)b * HW + pix) * C + c]);
+    }
+}
+
+inline int grid_for(size_t work, int block, int cap = 256 * 8) {
+    size_t g = (work + block - 1) / block;
+    if (g < 1) g = 1;
+    return (int)(g > (size_t)cap ? cap : g);
+}
+
+}  // namespace
+
+#define STREAM hipStream_t stream = (hipStream_t)stream_
+
+extern "C" int dig_gn_finalize(const dig_gn_finalize_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->stats && a->gamma && a->beta && a->aff, DIG_EINVAL, "gn_finalize: null pointer");
+    DIG_CHECK(a->B > 0 && a->groups > 0 && a->C % a->groups == 0 && a->tiles > 0 && a->hw > 0, DIG_EINVAL, "gn_finalize: bad shape");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(a->B * a->groups), dim3(64), 0, stream, *a);
+    DIG_LAUNCH_CHECK("gn_finalize");
+    return DIG_OK;
+}
+
+extern "C" int dig_gn_silu_add(const dig_gn_silu_add_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->x && a->aff && a->out, DIG_EINVAL, "gn_silu_add: null pointer");
+    DIG_CHECK(a->C % 8 == 0 && a->B > 0 && a->HW > 0, DIG_EINVAL, "gn_silu_add: bad shape");
+    const size_t work = (size_t)a->B * a->HW * (a->C / 8);
+    const int g = grid_for(work, 256);
+    if (a->dtype == DIG_BF16) hipLaunchKernelGGL(gn_silu_add_kernel<bf16>, dim3(g), dim3(256), 0, stream, *a);
+    else hipLaunchKernelGGL(gn_silu_add_kernel<float>, dim3(g), dim3(256), 0, stream, *a);
+    DIG_LAUNCH_CHECK("gn_silu_add");
+    return DIG_OK;
+}
+
+template <typename T> static void launch_rms(const dig_rmsnorm_args* a, hipStream_t stream) {
+    const int cv = a->C / 8;
+    int G = 64;
+    while (G > 1 && G / 2 >= cv) G /= 2;  // smallest power of two >= cv, capped at 64
+    const int rows_per_block = 256 / G;
+    const int g = grid_for((size_t)((a->rows + rows_per_block - 1) / rows_per_block), 1);
+    switch (G) {
+#define CASE(GG) case GG: hipLaunchKernelGGL((rmsnorm_kernel<T, GG>), dim3(g), dim3(256), 0, stream, *a); break;
+        CASE(1) CASE(2) CASE(4) CASE(8) CASE(16) CASE(32) CASE(64)
+#undef CASE
+    }
+}
+extern "C" int dig_rmsnorm(const dig_rmsnorm_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->x && a->g && a->out, DIG_EINVAL, "rmsnorm: null pointer");
+    DIG_CHECK(a->C % 8 == 0 && a->rows > 0, DIG_EINVAL, "rmsnorm: bad shape");
+    if (a->dtype == DIG_BF16) launch_rms<bf16>(a, stream);
+    else launch_rms<float>(a, stream);
+    DIG_LAUNCH_CHECK("rmsnorm");
+    return DIG_OK;
+}
+
+extern "C" int dig_row_softmax(const dig_row_softmax_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->in && a->out && a->rows > 0 && a->n > 0, DIG_EINVAL, "row_softmax: bad argument");
+    DIG_CHECK(a->rows < 2147483647LL, DIG_EINVAL, "row_softmax: too many rows");
+    const dim3 g((unsigned)a->rows), b(256);
+    if (a->dtype == DIG_BF16) {
+        if (a->in_f32) hipLaunchKernelGGL((row_softmax_kernel<float, bf16>), g, b, 0, stream, (const float*)a->in, (bf16*)a->out, a->n);
+        else hipLaunchKernelGGL((row_softmax_kernel<bf16, bf16>), g, b, 0, stream, (const bf16*)a->in, (bf16*)a->out, a->n);
+    } else {
+        hipLaunchKernelGGL((row_softmax_kernel<float, float>), g, b, 0, stream, (const float*)a->in, (float*)a->out, a->n);
+    }
+    DIG_LAUNCH_CHECK("row_softmax");
+    return DIG_OK;
+}
+
+extern "C" int dig_group_softmax32(const dig_group_softmax32_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->q && a->rows > 0 && a->groups > 0, DIG_EINVAL, "group_softmax32: bad argument");
+    const int g = grid_for((size_t)a->rows * a->groups, 256);
+    if (a->dtype == DIG_BF16) hipLaunchKernelGGL(group_softmax32_kernel<bf16>, dim3(g), dim3(256), 0, stream, *a);
+    else hipLaunchKernelGGL(group_softmax32_kernel<float>, dim3(g), dim3(256), 0, stream, *a);
+    DIG_LAUNCH_CHECK("group_softmax32");
+    return DIG_OK;
+}
+
+extern "C" int dig_row_max(const dig_row_max_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->in && a->out && a->rows > 0 && a->n > 0 && a->n % 8 == 0 && a->group_rows > 0, DIG_EINVAL, "row_max: bad argument");
+    if (a->dtype == DIG_BF16) hipLaunchKernelGGL(row_max_kernel<bf16>, dim3((unsigned)a->rows), dim3(256), 0, stream, *a);
+    else hipLaunchKernelGGL(row_max_kernel<float>, dim3((unsigned)a->rows), dim3(256), 0, stream, *a);
+    DIG_LAUNCH_CHECK("row_max");
+    return DIG_OK;
+}
+
+extern "C" int dig_sched_axpby(const dig_sched_axpby_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->x && a->y && a->t && a->sqrt_ac && a->sqrt_1mac && a->out, DIG_EINVAL, "sched_axpby: null pointer");
+    hipLaunchKernelGGL(sched_axpby_kernel, dim3(grid_for((size_t)a->B * 3 * a->HW, 256)), dim3(256), 0, stream, *a);
+    DIG_LAUNCH_CHECK("sched_axpby");
+    return DIG_OK;
+}
+
+extern "C" int dig_sinusoid(const dig_sinusoid_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->t && a->out && a->B > 0 && a->dim >= 4 && a->dim % 2 == 0, DIG_EINVAL, "sinusoid: bad argument");
+    const int g = cdiv(a->B * a->dim, 256);
+    if (a->dtype == DIG_BF16) hipLaunchKernelGGL(sinusoid_kernel<bf16>, dim3(g), dim3(256), 0, stream, *a);
+    else hipLaunchKernelGGL(sinusoid_kernel<float>, dim3(g), dim3(256), 0, stream, *a);
+    DIG_LAUNCH_CHECK("sinusoid");
+    return DIG_OK;
+}
+
+extern "C" int dig_act(const dig_act_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->in && a->out && a->n > 0, DIG_EINVAL, "act: bad argument");
+    const dim3 g(grid_for((size_t)a->n, 256)), b(256);
+    const bool bf = a->dtype == DIG_BF16;
+    const bool fi = a->in_f32 || !bf, fo = a->out_f32 || !bf;
+    if (fi && fo) hipLaunchKernelGGL((act_kernel<float, float>), g, b, 0, stream, (const float*)a->in, (float*)a->out, a->n, a->act);
+    else if (fi) hipLaunchKernelGGL((act_kernel<float, bf16>), g, b, 0, stream, (const float*)a->in, (bf16*)a->out, a->n, a->act);
+    else if (fo) hipLaunchKernelGGL((act_kernel<bf16, float>), g, b, 0, stream, (const bf16*)a->in, (float*)a->out, a->n, a->act);
+    else hipLaunchKernelGGL((act_kernel<bf16, bf16>), g, b, 0, stream, (const bf16*)a->in, (bf16*)a->out, a->n, a->act);
+    DIG_LAUNCH_CHECK("act");
+    return DIG_OK;
+}
+
+extern "C" int dig_bilinear_ac_concat(const dig_bilinear_ac_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->in && a->out, DIG_EINVAL, "bilinear_ac: null pointer");
+    DIG_CHECK(a->h > 0 && a->w > 0 && a->c_off >= 0 && a->c_off + a->C <= a->Ctot, DIG_EINVAL, "bilinear_ac: bad geometry");
+    const int g = grid_for((size_t)a->B * a->h * a->w * a->C, 256);
+    if (a->dtype == DIG_BF16) hipLaunchKernelGGL(bilinear_ac_kernel<bf16>, dim3(g), dim3(256), 0, stream, *a);
+    else hipLaunchKernelGGL(bilinear_ac_kernel<float>, dim3(g), dim3(256), 0, stream, *a);
+    DIG_LAUNCH_CHECK("bilinear_ac");
+    return DIG_OK;
+}
+
+extern "C" int dig_nchw_f32_to_nhwc(const dig_layout_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->in && a->out, DIG_EINVAL, "layout: null pointer");
+    const int g = grid_for((size_t)a->B * a->C * a->HW, 256);
+    if (a->dtype == DIG_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16>, dim3(g), dim3(256), 0, stream, (const float*)a->in, (bf16*)a->out, a->B, a->C, a->HW);
+    else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)a->in, (float*)a->out, a->B, a->C, a->HW);
+    DIG_LAUNCH_CHECK("nchw_to_nhwc");
+    return DIG_OK;
+}
+extern "C" int dig_nhwc_to_nchw_f32(const dig_layout_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->in && a->out, DIG_EINVAL, "layout: null pointer");
+    const int g = grid_for((size_t)a->B * a->C * a->HW, 256);
+    if (a->dtype == DIG_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16>, dim3(g), dim3(256), 0, stream, (const bf16*)a->in, (float*)a->out, a->B, a->C, a->HW);
+    else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)a->in, (float*)a->out, a->B, a->C, a->HW);
+    DIG_LAUNCH_CHECK("nhwc_to_nchw");
+    return DIG_OK;
+}

@@ -1,0 +1,534 @@
+"""MI355X-native drop-in for the DiG diffusion-guidance forward: ``Unet``, ``GaussianDiffusion``, ``Attend``.
+
+Public surface and ``state_dict`` keys follow the reference (denoising_diffusion_pytorch/
+denoising_diffusion_pytorch.py:268-448, 493-634, 853-913 and attend.py:35-113) so its checkpoints load
+unchanged, but the modules below are parameter containers only: every forward is executed by the
+hand-written gfx950 kernels in dig_amd/csrc through the C ABI of include/dig_hip.h.  There is no
+CPU/eager fallback - calling a forward off-device or without libdig_hip.so raises.
+
+Data flow of one Unet forward (activations NHWC, bf16 or fp32 storage, fp32 accumulate/statistics):
+  stem kernel      : normalise + q_sample + conv7x7                       (one pass, writes x_t too)
+  time MLP         : sinusoid -> 2 linears -> ONE GEMM for all 19 per-block (scale|shift) projections
+  ResnetBlock      : conv3x3 [+concat] -> GN partials -> finalize -> conv3x3 with GN+SS+SiLU fused into
+                     its loader -> finalize -> (GN+SiLU + residual) fused into res_conv GEMM / one ew pass
+  LinearAttention  : RMSNorm -> q GEMM + 32-wide softmax; k,v projected channel-major -> context on MFMA
+                     with exp fused -> out GEMM -> to_out GEMM -> RMSNorm + residual
+  Attention        : RMSNorm -> qk GEMM, v channel-major -> QK^T GEMM (fp32 logits) -> row softmax -> PV GEMM
+                     -> to_out GEMM + residual
+  guidance maps    : bilinear(align_corners=True) written straight into the [B,1024,h,w] concat buffer
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+from ._lib import call, dtype_code
+
+__all__ = ["Unet", "GaussianDiffusion", "Attend", "sigmoid_beta_schedule"]
+
+
+# --------------------------------------------------------------------------------------------------
+# parameter containers (names chosen to reproduce the reference state_dict keys)
+# --------------------------------------------------------------------------------------------------
+class _NoForward(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError(f"{type(self).__name__} is a parameter container; run the enclosing Unet on a HIP device")
+
+
+class _Marker(_NoForward):
+    """Parameter-free placeholder that keeps nn.Sequential indices aligned with the reference."""
+
+
+class RMSNorm(_NoForward):
+    def __init__(self, dim):
+        super().__init__()
+        self.g = nn.Parameter(torch.ones(1, dim, 1, 1))
+
+
+class Block(_NoForward):
+    def __init__(self, dim, dim_out, groups=8):
+        super().__init__()
+        self.proj = nn.Conv2d(dim, dim_out, 3, padding=1)
+        self.norm = nn.GroupNorm(groups, dim_out)
+
+
+class ResnetBlock(_NoForward):
+    def __init__(self, dim, dim_out, *, time_emb_dim=None, groups=8):
+        super().__init__()
+        self.mlp = nn.Sequential(_Marker(), nn.Linear(time_emb_dim, dim_out * 2)) if time_emb_dim is not None else None
+        self.block1 = Block(dim, dim_out, groups)
+        self.block2 = Block(dim_out, dim_out, groups)
+        self.res_conv = nn.Conv2d(dim, dim_out, 1) if dim != dim_out else _Marker()
+
+
+class LinearAttention(_NoForward):
+    def __init__(self, dim, heads=4, dim_head=32):
+        super().__init__()
+        self.heads, self.dim_head = heads, dim_head
+        hidden = heads * dim_head
+        self.norm = RMSNorm(dim)
+        self.to_qkv = nn.Conv2d(dim, hidden * 3, 1, bias=False)
+        self.to_out = nn.Sequential(nn.Conv2d(hidden, dim, 1), RMSNorm(dim))
+
+
+class Attention(_NoForward):
+    def __init__(self, dim, heads=4, dim_head=32, flash=False):
+        super().__init__()
+        self.heads, self.dim_head = heads, dim_head
+        hidden = heads * dim_head
+        self.norm = RMSNorm(dim)
+        self.attend = Attend(flash=flash)
+        self.to_qkv = nn.Conv2d(dim, hidden * 3, 1, bias=False)
+        self.to_out = nn.Conv2d(hidden, dim, 1)
+
+
+class Attend(nn.Module):
+    """attend.py:35-113.  forward(q, k, v) with [b, h, n, d] tensors -> [b, h, n, d], softmax(q k^T / sqrt(d)) v.
+    `flash` is accepted for API compatibility; both settings run the same HIP kernels."""
+
+    def __init__(self, dropout=0., flash=False):
+        super().__init__()
+        self.dropout, self.flash = dropout, flash
+
+    def forward(self, q, k, v):
+        if self.training and self.dropout > 0:
+            raise NotImplementedError("attention dropout is a training feature outside the guidance path")
+        assert q.is_cuda, "dig_amd.Attend runs on the HIP device only"
+        b, h, n, d = q.shape
+        nk = k.shape[-2]
+        assert d % 8 == 0 and nk % 8 == 0, "head dim and key length must be multiples of 8"
+        dt = q.dtype
+        q, k = q.contiguous(), k.contiguous()
+        vT = v.transpose(-1, -2).contiguous()  # [b,h,d,nk]: PV contracts over keys, so keys must be contiguous
+        S = torch.empty(b * h, n, nk, dtype=torch.float32, device=q.device)
+        ops.gemm_nt(q, k, S, n, nk, d, dtype=dt, alpha=d ** -0.5, out_f32=True, batch=b * h,
+                    sa=(n * d, 0), sb=(nk * d, 0), sc=(n * nk, 0))
+        P = ops.row_softmax(S, dt)
+        out = torch.empty(b, h, n, d, dtype=dt, device=q.device)
+        ops.gemm_nt(P, vT, out, n, d, nk, dtype=dt, batch=b * h, sa=(n * nk, 0), sb=(d * nk, 0), sc=(n * d, 0))
+        return out
+
+
+def _down(dim, dim_out):
+    return nn.Sequential(_Marker(), nn.Conv2d(dim * 4, dim_out, 1))
+
+
+def _up(dim, dim_out):
+    return nn.Sequential(_Marker(), nn.Conv2d(dim, dim_out, 3, padding=1))
+
+
+class Unet(nn.Module):
+    """Same constructor as the reference Unet (ddp.py:268-286).  Supported on the HIP path: the DiG
+    configuration family - channels=3, no self-conditioning / learned variance / learned sinusoidal
+    embedding, dim a multiple of 16, attn_dim_head=32."""
+
+    def __init__(self, dim, init_dim=None, out_dim=None, dim_mults=(1, 2, 4, 8), channels=3, self_condition=False,
+                 resnet_block_groups=8, learned_variance=False, learned_sinusoidal_cond=False,
+                 random_fourier_features=False, learned_sinusoidal_dim=16, attn_dim_head=32, attn_heads=4,
+                 full_attn=(False, False, False, True), flash_attn=False):
+        super().__init__()
+        if self_condition or learned_variance or learned_sinusoidal_cond or random_fourier_features:
+            raise NotImplementedError("only the DiG Unet configuration (plain sinusoidal time embedding, "
+                                      "no self-conditioning, no learned variance) has a HIP path")
+        if channels != 3 or attn_dim_head != 32 or dim % 16 != 0 or (init_dim not in (None, dim)):
+            raise NotImplementedError("HIP path needs channels=3, attn_dim_head=32, init_dim=dim, dim % 16 == 0")
+        self.channels, self.self_condition = channels, self_condition
+        self.random_or_learned_sinusoidal_cond = False
+        self.dim, self.groups = dim, resnet_block_groups
+        self.init_conv = nn.Conv2d(channels, dim, 7, padding=3)
+        dims = [dim] + [dim * m for m in dim_mults]
+        pairs = list(zip(dims[:-1], dims[1:]))
+        n = len(pairs)
+        tdim = dim * 4
+        self.time_mlp = nn.Sequential(_Marker(), nn.Linear(dim, tdim), _Marker(), nn.Linear(tdim, tdim))
+        as_tuple = lambda v: v if isinstance(v, tuple) else (v,) * n
+        full_attn, attn_heads = as_tuple(full_attn), as_tuple(attn_heads)
+        assert len(full_attn) == n
+        self.full_attn, self.heads = full_attn, attn_heads
+        rb = lambda i, o: ResnetBlock(i, o, time_emb_dim=tdim, groups=resnet_block_groups)
+        att = lambda full, d, hd: Attention(d, heads=hd, flash=flash_attn) if full else LinearAttention(d, heads=hd)
+        self.downs = nn.ModuleList()
+        for i, (ci, co) in enumerate(pairs):
+            last = i == n - 1
+            self.downs.append(nn.ModuleList([rb(ci, ci), rb(ci, ci), att(full_attn[i], ci, attn_heads[i]),
+                                             _down(ci, co) if not last else nn.Conv2d(ci, co, 3, padding=1)]))
+        mid = dims[-1]
+        self.mid_block1 = rb(mid, mid)
+        self.mid_attn = Attention(mid, heads=attn_heads[-1], flash=flash_attn)
+        self.mid_block2 = rb(mid, mid)
+        self.ups = nn.ModuleList()
+        for j, i in enumerate(reversed(range(n))):
+            ci, co = pairs[i]
+            last = j == n - 1
+            self.ups.append(nn.ModuleList([rb(co + ci, co), rb(co + ci, co), att(full_attn[i], co, attn_heads[i]),
+                                           _up(co, ci) if not last else nn.Conv2d(co, ci, 3, padding=1)]))
+        self.out_dim = out_dim if out_dim is not None else channels
+        self.final_res_block = rb(dim * 2, dim)
+        self.final_conv = nn.Conv2d(dim, self.out_dim, 1)
+        self.compute_dtype = torch.bfloat16  # storage type of activations/weights on the HIP path
+        self._packed = None
+
+    @property
+    def downsample_factor(self):
+        return 2 ** (len(self.downs) - 1)
+
+    # ---- weight packing ---------------------------------------------------------------------
+    def set_compute_dtype(self, dtype):
+        assert dtype in (torch.bfloat16, torch.float32)
+        self.compute_dtype = dtype
+        self._packed = None
+        return self
+
+    def _pack_key(self):
+        p = next(self.parameters())
+        return (p.device, self.compute_dtype, sum(q._version for q in self.parameters()), p.data_ptr())
+
+    def packed(self):
+        key = self._pack_key()
+        if self._packed is None or self._packed["key"] != key:
+            self._packed = _pack_unet(self, self.compute_dtype)
+            self._packed["key"] = key
+        return self._packed
+
+    # ---- forward ----------------------------------------------------------------------------
+    def forward(self, x, time, x_self_cond=None):
+        """ddp.py:379-448: x [B,3,H,W] fp32 (already noised), time [B] int64.
+        Returns pred if self.training else (pred, [5 guidance maps])."""
+        assert x_self_cond is None, "self-conditioning is not part of the DiG configuration"
+        pred, feats, _ = _unet_forward(self, x, None, time, None, None, (1.0,) * 3, (0.0,) * 3, want_xt=False)
+        return pred if self.training else (pred, feats)
+
+
+def _conv3_pack(conv, dt):
+    return conv.weight.detach().permute(0, 2, 3, 1).contiguous().to(dt), conv.bias.detach().float().contiguous()
+
+
+def _conv1_pack(conv, dt):
+    w = conv.weight.detach().reshape(conv.weight.shape[0], -1).contiguous().to(dt)
+    return w, (conv.bias.detach().float().contiguous() if conv.bias is not None else None)
+
+
+def _pack_unet(u, dt):
+    f32 = lambda t: t.detach().float().contiguous()
+    P = {"dtype": dt}
+    P["stem_w"] = f32(u.init_conv.weight.permute(2, 3, 1, 0).reshape(147, -1))  # [tap][c][Cout]
+    P["stem_b"] = f32(u.init_conv.bias)
+    P["t1"] = (f32(u.time_mlp[1].weight), f32(u.time_mlp[1].bias))
+    P["t3"] = (f32(u.time_mlp[3].weight), f32(u.time_mlp[3].bias))
+    mlps_w, mlps_b, off = [], [], [0]
+
+    def rb(m):
+        d = {}
+        d["w1"], d["b1"] = _conv3_pack(m.block1.proj, dt)
+        d["g1"], d["be1"] = f32(m.block1.norm.weight), f32(m.block1.norm.bias)
+        d["w2"], d["b2"] = _conv3_pack(m.block2.proj, dt)
+        d["g2"], d["be2"] = f32(m.block2.norm.weight), f32(m.block2.norm.bias)
+        d["eps"] = m.block1.norm.eps
+        d["res"] = _conv1_pack(m.res_conv, dt) if isinstance(m.res_conv, nn.Conv2d) else None
+        d["ss_off"] = off[0]
+        mlps_w.append(f32(m.mlp[1].weight))
+        mlps_b.append(f32(m.mlp[1].bias))
+        off[0] += m.mlp[1].weight.shape[0]
+        return d
+
+    def attn(m):
+        d = {"full": isinstance(m, Attention), "heads": m.heads}
+        hid = m.heads * m.dim_head
+        wqkv, _ = _conv1_pack(m.to_qkv, dt)
+        d["g"] = f32(m.norm.g.reshape(-1))
+        if d["full"]:
+            d["wqk"], d["wv"] = wqkv[:2 * hid].contiguous(), wqkv[2 * hid:].contiguous()
+            d["wo"], d["bo"] = _conv1_pack(m.to_out, dt)
+        else:
+            d["wq"], d["wkv"] = wqkv[:hid].contiguous(), wqkv[hid:].contiguous()
+            d["wo"], d["bo"] = _conv1_pack(m.to_out[0], dt)
+            d["g2"] = f32(m.to_out[1].g.reshape(-1))
+        return d
+
+    def stage(blocks, is_down):
+        b1, b2, at, smp = blocks
+        d = {"rb1": rb(b1), "rb2": rb(b2), "attn": attn(at)}
+        if isinstance(smp, nn.Conv2d):
+            d["kind"] = "conv"
+            d["w"], d["b"] = _conv3_pack(smp, dt)
+        elif is_down:
+            d["kind"] = "down"
+            w = smp[1].weight.detach()
+            co, c4 = w.shape[0], w.shape[1]
+            d["w"] = w.reshape(co, c4 // 4, 2, 2).permute(0, 2, 3, 1).reshape(co, c4).contiguous().to(dt)
+            d["b"] = f32(smp[1].bias)
+        else:
+            d["kind"] = "up"
+            d["w"], d["b"] = _conv3_pack(smp[1], dt)
+        return d
+
+    P["downs"] = [stage(s, True) for s in u.downs]
+    P["mid1"], P["mid_attn"], P["mid2"] = rb(u.mid_block1), attn(u.mid_attn), rb(u.mid_block2)
+    P["ups"] = [stage(s, False) for s in u.ups]
+    P["final_rb"] = rb(u.final_res_block)
+    P["final_w"], P["final_b"] = _conv1_pack(u.final_conv, dt)
+    P["mlp_w"], P["mlp_b"] = torch.cat(mlps_w, 0).contiguous(), torch.cat(mlps_b, 0).contiguous()
+    dev = u.init_conv.weight.device
+    P["one"] = torch.ones(1, dtype=torch.float32, device=dev)
+    P["zero"] = torch.zeros(1, dtype=torch.float32, device=dev)
+    return P
+
+
+# --------------------------------------------------------------------------------------------------
+# forward building blocks (all on the current HIP stream)
+# --------------------------------------------------------------------------------------------------
+def _resnet(p, x0, x1, ss_all, debug=None):
+    """ResnetBlock (ddp.py:169-194); x1 = second half of a fused channel concat (or None)."""
+    hw = x0.shape[1] * x0.shape[2]
+    c1, st1 = ops.conv3x3(x0, p["w1"], p["b1"], x1=x1)
+    aff1 = ops.gn_finalize(st1, p["g1"], p["be1"], hw, ss=ss_all, ss_off=p["ss_off"], eps=p["eps"])
+    c2, st2 = ops.conv3x3(c1, p["w2"], p["b2"], aff=aff1)
+    aff2 = ops.gn_finalize(st2, p["g2"], p["be2"], hw, eps=p["eps"])
+    if p["res"] is None:
+        assert x1 is None
+        return ops.gn_silu_add(c2, aff2, res=x0)
+    wr, br = p["res"]
+    return ops.linear_rows(x0, wr, bias=br, x1=x1, gsrc=c2, gaff=aff2, rows_per_img=hw)
+
+
+def _linear_attention(p, x):
+    """LinearAttention (ddp.py:196-233) + the caller's residual (ddp.py:402,430)."""
+    B, H, W, C = x.shape
+    n, heads = H * W, p["heads"]
+    hid = heads * 32
+    dt = x.dtype
+    assert n % 8 == 0, "H*W must be a multiple of 8 at every linear-attention level"
+    xn = ops.rmsnorm(x, p["g"])
+    q = ops.linear_rows(xn, p["wq"])  # [B,H,W,hid] pixel-major
+    ops.group_softmax32_(q, 32 ** -0.5)
+    kvT = torch.empty(B, 2 * hid, n, dtype=dt, device=x.device)  # channel-major k | v
+    ops.gemm_nt(p["wkv"], xn, kvT, 2 * hid, n, C, dtype=dt, batch=B, sb=(n * C, 0), sc=(2 * hid * n, 0))
+    kmax = torch.empty(B * hid, dtype=torch.float32, device=x.device)
+    call("row_max", **{"in": kvT}, out=kmax, rows=B * hid, group_stride=2 * hid * n, group_rows=hid, n=n, dtype=dtype_code(dt))
+    chunks = (n + 63) // 64
+    splits = max(1, min(64, chunks // 8))
+    part = torch.empty(B * heads, splits, 32, 32, dtype=torch.float32, device=x.device)
+    ksum = torch.empty(B * heads, splits, 32, dtype=torch.float32, device=x.device)
+    esz = kvT.element_size()
+    call("la_context", k=kvT.data_ptr(), v=kvT.data_ptr() + hid * n * esz, kmax=kmax, part=part, ksum=ksum,
+         b_stride_k=2 * hid * n, h_stride_k=32 * n, b_stride_v=2 * hid * n, h_stride_v=32 * n,
+         B=B, heads=heads, n=n, splits=splits, dtype=dtype_code(dt))
+    ctxT = torch.empty(B * heads, 32, 32, dtype=dt, device=x.device)
+    call("la_finalize", part=part, ksum=ksum, ctxT=ctxT, BH=B * heads, splits=splits, dtype=dtype_code(dt), scale=1.0)
+    att = torch.empty(B, H, W, hid, dtype=dt, device=x.device)
+    ops.gemm_nt(q, ctxT, att, n, 32, 32, dtype=dt, lda0=hid, ldb=32, ldc=hid, batch=B * heads, z_inner=heads,
+                sa=(n * hid, 32), sb=(heads * 1024, 1024), sc=(n * hid, 32))
+    y = ops.linear_rows(att, p["wo"], bias=p["bo"])
+    return ops.rmsnorm(y, p["g2"], res=x)
+
+
+def _full_attention(p, x):
+    """Attention (ddp.py:235-264) via Attend (attend.py:98-113) + the caller's residual (ddp.py:402,412,430)."""
+    B, H, W, C = x.shape
+    n, heads = H * W, p["heads"]
+    hid = heads * 32
+    dt = x.dtype
+    assert n % 8 == 0, "H*W must be a multiple of 8 at every full-attention level"
+    xn = ops.rmsnorm(x, p["g"])
+    qk = ops.linear_rows(xn, p["wqk"])  # [B,H,W,2*hid]: q | k, pixel-major
+    vT = torch.empty(B, hid, n, dtype=dt, device=x.device)
+    ops.gemm_nt(p["wv"], xn, vT, hid, n, C, dtype=dt, batch=B, sb=(n * C, 0), sc=(hid * n, 0))
+    S = torch.empty(B * heads, n, n, dtype=torch.float32, device=x.device)
+    ops.gemm_nt(qk, (qk, hid), S, n, n, 32, dtype=dt, lda0=2 * hid, ldb=2 * hid, ldc=n, alpha=32 ** -0.5, out_f32=True,
+                batch=B * heads, z_inner=heads, sa=(n * 2 * hid, 32), sb=(n * 2 * hid, 32), sc=(heads * n * n, n * n))
+    Pm = ops.row_softmax(S, dt)
+    att = torch.empty(B, H, W, hid, dtype=dt, device=x.device)
+    ops.gemm_nt(Pm, vT, att, n, 32, n, dtype=dt, lda0=n, ldb=n, ldc=hid, batch=B * heads, z_inner=heads,
+                sa=(heads * n * n, n * n), sb=(hid * n, 32 * n), sc=(n * hid, 32))
+    return ops.linear_rows(att, p["wo"], bias=p["bo"], res=x)
+
+
+def _time_embedding(u, P, t):
+    """ddp.py:118-130,316-321 and every block's SiLU+Linear (ddp.py:172-175,186-188); always fp32 (tiny)."""
+    B = t.shape[0]
+    emb = torch.empty(B, u.dim, dtype=torch.float32, device=t.device)
+    call("sinusoid", t=t, out=emb, B=B, dim=u.dim, dtype=dtype_code(torch.float32))
+    e = ops.linear_rows(emb, P["t1"][0], bias=P["t1"][1], gelu=True)
+    temb = ops.linear_rows(e, P["t3"][0], bias=P["t3"][1])
+    st = torch.empty_like(temb)
+    call("act", **{"in": temb}, out=st, n=temb.numel(), act=0, in_f32=1, out_f32=1, dtype=dtype_code(torch.float32))
+    return temb, ops.linear_rows(st, P["mlp_w"], bias=P["mlp_b"])  # [B, sum 2*C] fp32
+
+
+def _unet_forward(u, img, noise, t, sqrt_ac, sqrt_1mac, pre_scale, pre_shift, want_xt, debug=None):
+    """Shared body of Unet.forward and GaussianDiffusion.p_losses.  img [B,3,H,W] fp32 NCHW.
+    With noise=None the stem runs with (1, 0) coefficients, i.e. x_t = pre(img)."""
+    if not img.is_cuda:
+        raise RuntimeError("dig_amd.Unet runs on the HIP device only (no CPU fallback); move inputs with .cuda()")
+    B, Cin, H, W = img.shape
+    f = u.downsample_factor
+    assert H % f == 0 and W % f == 0, f"your input dimensions {(H, W)} need to be divisible by {f}, given the unet"
+    P = u.packed()
+    dt = P["dtype"]
+    dev = img.device
+    img = img.contiguous().float()
+    t = t.to(device=dev, dtype=torch.long).contiguous()
+    if noise is None:
+        noise, tt, ca, cs = img, torch.zeros_like(t), P["one"], P["zero"]
+    else:
+        noise, tt, ca, cs = noise.contiguous().float(), t, sqrt_ac, sqrt_1mac
+    x_t = torch.empty_like(img) if want_xt else None
+    x = torch.empty(B, H, W, u.dim, dtype=dt, device=dev)
+    call("qsample_stem", img=img, noise=noise, t=tt, sqrt_ac=ca, sqrt_1mac=cs, w=P["stem_w"], bias=P["stem_b"],
+         x_t=x_t, out=x, pre_scale=pre_scale, pre_shift=pre_shift, B=B, H=H, W=W, Cout=u.dim, dtype=dtype_code(dt))
+    keep = (lambda k, v: debug.__setitem__(k, v)) if debug is not None else (lambda k, v: None)
+    keep("init_conv", x)
+    r = x
+    temb, ss = _time_embedding(u, P, t)
+    keep("temb", temb)
+    skips = []
+    for i, s in enumerate(P["downs"]):
+        x = _resnet(s["rb1"], x, None, ss)
+        skips.append(x)
+        x = _resnet(s["rb2"], x, None, ss)
+        x = _full_attention(s["attn"], x) if s["attn"]["full"] else _linear_attention(s["attn"], x)
+        skips.append(x)
+        keep(f"downs.{i}.attn", x)
+        if s["kind"] == "down":
+            x = ops.downsample_conv(x, s["w"], s["b"])
+        else:
+            x, _ = ops.conv3x3(x, s["w"], s["b"], want_stats=False)
+        keep(f"downs.{i}.out", x)
+    x = _resnet(P["mid1"], x, None, ss)
+    x = _full_attention(P["mid_attn"], x)
+    x = _resnet(P["mid2"], x, None, ss)
+    keep("mid", x)
+    h, w = H // 16, W // 16
+    chans = [x.shape[-1]] + [s["w"].shape[0] for s in P["ups"]]
+    maps = torch.empty(B, sum(chans), h, w, dtype=torch.float32, device=dev)
+    ops.bilinear_ac_into(x, maps, 0)
+    coff = chans[0]
+    for j, s in enumerate(P["ups"]):
+        x = _resnet(s["rb1"], x, skips.pop(), ss)
+        x = _resnet(s["rb2"], x, skips.pop(), ss)
+        x = _full_attention(s["attn"], x) if s["attn"]["full"] else _linear_attention(s["attn"], x)
+        keep(f"ups.{j}.attn", x)
+        x, _ = ops.conv3x3(x, s["w"], s["b"], up2=(s["kind"] == "up"), want_stats=False)
+        keep(f"ups.{j}.out", x)
+        ops.bilinear_ac_into(x, maps, coff)
+        coff += chans[j + 1]
+    x = _resnet(P["final_rb"], x, r, ss)
+    pred = torch.empty(B, u.out_dim, H, W, dtype=torch.float32, device=dev)
+    ops.gemm_nt(x, P["final_w"], pred, B * H * W, u.out_dim, u.dim, dtype=dt, bias=P["final_b"], out_f32=True, nchw_hw=H * W)
+    feats, o = [], 0
+    for c in chans:
+        feats.append(maps[:, o:o + c])
+        o += c
+    u._last_maps = maps  # contiguous [B, sum C, h, w] == torch.cat(feats, 1)
+    return pred, feats, x_t
+
+
+# --------------------------------------------------------------------------------------------------
+# GaussianDiffusion (schedule + q_sample + p_losses eval + predict_start_from_v)
+# --------------------------------------------------------------------------------------------------
+def sigmoid_beta_schedule(timesteps, start=-3, end=3, tau=1):
+    """ddp.py:478-491, computed in fp64."""
+    t = torch.linspace(0, timesteps, timesteps + 1, dtype=torch.float64) / timesteps
+    v_start, v_end = torch.tensor(start / tau).sigmoid(), torch.tensor(end / tau).sigmoid()
+    ac = (-((t * (end - start) + start) / tau).sigmoid() + v_end) / (v_end - v_start)
+    ac = ac / ac[0]
+    return torch.clip(1 - ac[1:] / ac[:-1], 0, 0.999)
+
+
+class GaussianDiffusion(nn.Module):
+    """ddp.py:493-634, 853-913 - the subset DiG calls (model.py:132-143, 288, 302-306): schedule buffers with the
+    reference's names, normalize/unnormalize, q_sample, p_losses (eval branch), predict_start_from_v.
+    Samplers and the training loss are outside the guidance path and are not provided."""
+
+    def __init__(self, model, *, image_size, timesteps=1000, sampling_timesteps=None, objective='pred_v',
+                 beta_schedule='sigmoid', schedule_fn_kwargs=dict(), ddim_sampling_eta=0., auto_normalize=True,
+                 offset_noise_strength=0., min_snr_loss_weight=False, min_snr_gamma=5):
+        super().__init__()
+        assert model.channels == model.out_dim
+        assert not model.random_or_learned_sinusoidal_cond
+        if objective != 'pred_v' or beta_schedule != 'sigmoid':
+            raise NotImplementedError("the DiG checkpoint uses objective='pred_v' with the sigmoid schedule")
+        self.model = model
+        self.channels, self.self_condition = model.channels, model.self_condition
+        self.image_size, self.objective = image_size, objective
+        betas = sigmoid_beta_schedule(timesteps, **schedule_fn_kwargs)
+        alphas = 1. - betas
+        ac = torch.cumprod(alphas, dim=0)
+        acp = torch.cat([torch.ones(1, dtype=torch.float64), ac[:-1]])
+        self.num_timesteps = int(betas.shape[0])
+        self.sampling_timesteps = sampling_timesteps if sampling_timesteps is not None else timesteps
+        assert self.sampling_timesteps <= timesteps
+        self.is_ddim_sampling = self.sampling_timesteps < timesteps
+        self.ddim_sampling_eta = ddim_sampling_eta
+        self.offset_noise_strength = offset_noise_strength
+        pv = betas * (1. - acp) / (1. - ac)
+        snr = ac / (1 - ac)
+        clipped = snr.clone()
+        if min_snr_loss_weight:
+            clipped.clamp_(max=min_snr_gamma)
+        for name, val in [
+            ('betas', betas), ('alphas_cumprod', ac), ('alphas_cumprod_prev', acp),
+            ('sqrt_alphas_cumprod', ac.sqrt()), ('sqrt_one_minus_alphas_cumprod', (1. - ac).sqrt()),
+            ('log_one_minus_alphas_cumprod', (1. - ac).log()), ('sqrt_recip_alphas_cumprod', (1. / ac).sqrt()),
+            ('sqrt_recipm1_alphas_cumprod', (1. / ac - 1).sqrt()), ('posterior_variance', pv),
+            ('posterior_log_variance_clipped', pv.clamp(min=1e-20).log()),
+            ('posterior_mean_coef1', betas * acp.sqrt() / (1. - ac)),
+            ('posterior_mean_coef2', (1. - acp) * alphas.sqrt() / (1. - ac)),
+            ('loss_weight', clipped / (snr + 1)),
+        ]:
+            self.register_buffer(name, val.to(torch.float32))
+        self.auto_normalize = auto_normalize
+
+    @property
+    def device(self):
+        return self.betas.device
+
+    def normalize(self, img):
+        return img * 2 - 1 if self.auto_normalize else img
+
+    def unnormalize(self, t):
+        return (t + 1) * 0.5 if self.auto_normalize else t
+
+    def _axpby(self, x, y, t, sign, post_scale=(1.0,) * 3, post_shift=(0.0,) * 3):
+        assert x.is_cuda, "dig_amd.GaussianDiffusion runs on the HIP device only"
+        B, C, H, W = x.shape
+        assert C == 3
+        out = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
+        call("sched_axpby", x=x.contiguous().float(), y=y.contiguous().float(), t=t.to(torch.long).contiguous(),
+             sqrt_ac=self.sqrt_alphas_cumprod, sqrt_1mac=self.sqrt_one_minus_alphas_cumprod, out=out,
+             post_scale=post_scale, post_shift=post_shift, sign=sign, B=B, HW=H * W)
+        return out
+
+    def q_sample(self, x_start, t, noise=None):
+        """ddp.py:853-860."""
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        return self._axpby(x_start, noise, t, 1.0)
+
+    def predict_start_from_v(self, x_t, t, v):
+        """ddp.py:630-634."""
+        return self._axpby(x_t, v, t, -1.0)
+
+    def p_losses(self, x_start, t, noise=None, offset_noise_strength=None, pre_scale=(1.0,) * 3, pre_shift=(0.0,) * 3):
+        """Eval branch of ddp.py:862-913: returns (x_t, model_out, feat_out).  The discarded MSE of the reference
+        (ddp.py:896-909) is not computed.  pre_scale/pre_shift fuse a per-channel affine on x_start into the stem
+        (used by dig_amd.guidance to fold denormforDiff + normalize)."""
+        if self.model.training:
+            raise NotImplementedError("the training loss is outside the guidance path; call .eval() first")
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        ons = offset_noise_strength if offset_noise_strength is not None else self.offset_noise_strength
+        if ons > 0.:
+            noise = noise + ons * torch.randn(x_start.shape[:2], device=x_start.device)[:, :, None, None]
+        pred, feats, x_t = _unet_forward(self.model, x_start, noise, t, self.sqrt_alphas_cumprod,
+                                         self.sqrt_one_minus_alphas_cumprod, pre_scale, pre_shift, want_xt=True)
+        return x_t, pred, feats
+
+    def forward(self, img, *args, **kwargs):
+        """ddp.py:915-925."""
+        b, c, h, w = img.shape
+        assert h == self.image_size and w == self.image_size, f'height and width of image must be {self.image_size}'
+        t = torch.randint(0, self.num_timesteps, (b,), device=img.device).long()
+        return self.p_losses(img, t, *args, pre_scale=(2.0,) * 3 if self.auto_normalize else (1.0,) * 3,
+                             pre_shift=(-1.0,) * 3 if self.auto_normalize else (0.0,) * 3, **kwargs)

@@ -1,0 +1,83 @@
+"""MCTformerV2_DiG (DeiT-small with C class tokens) - parameter tree with the reference's state_dict keys
+(networks/mctformer.py:171-192, networks/vision_transformer.py:54-103,177-196,226-278); the CAM forward
+(return_att=True) runs on the HIP kernels, see dig_amd/cam.py."""
+import torch
+from torch import nn
+
+__all__ = ["MCTformerV2_DiG", "create_model", "deit_small_MCTformerV2_DiG"]
+
+
+class _Holder(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container; run MCTformerV2_DiG.forward on a HIP device")
+
+
+class _Attn(_Holder):
+    def __init__(self, dim):
+        super().__init__()
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+
+
+class _Mlp(_Holder):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class _Block(_Holder):
+    def __init__(self, dim, mlp_ratio):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _Attn(dim)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+
+
+class _PatchEmbed(_Holder):
+    def __init__(self, patch, in_chans, dim):
+        super().__init__()
+        self.patch_size = (patch, patch)
+        self.proj = nn.Conv2d(in_chans, dim, kernel_size=patch, stride=patch)
+
+
+class MCTformerV2_DiG(nn.Module):
+    """`lfca=False` omits the LFCA0/LFCA1/diff_head_p parameters (191 M, training-only consumer of the guidance
+    maps); load reference checkpoints with strict=False in that case."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=20, embed_dim=384, depth=12, num_heads=6,
+                 mlp_ratio=4., lfca=False, **_ignored):
+        super().__init__()
+        self.num_classes, self.embed_dim, self.num_heads, self.depth = num_classes, embed_dim, num_heads, depth
+        self.patch_embed = _PatchEmbed(patch_size, in_chans, embed_dim)
+        self.num_patches = (img_size // patch_size) ** 2
+        self.cls_token = nn.Parameter(torch.zeros(1, num_classes, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.num_patches + num_classes, embed_dim))
+        self.blocks = nn.ModuleList([_Block(embed_dim, mlp_ratio) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)  # present in the checkpoint, unused by the DiG forward
+        self.head = nn.Conv2d(embed_dim, num_classes, kernel_size=3, stride=1, padding=1)
+        if lfca:
+            raise NotImplementedError("LFCA consumer is outside round-1 scope (SURVEY.md 8f-1)")
+        self._packed = None
+
+    def forward(self, x, feat_diff=None, return_att=False, n_layers=12, detach=True):
+        from . import cam
+        if feat_diff is not None:
+            raise NotImplementedError("the LFCA branch (training-only) is outside the guidance/CAM hot path")
+        outs = cam.mctformer_forward(self, x, n_layers)
+        return outs["rcams"] if return_att else outs
+
+
+def deit_small_MCTformerV2_DiG(pretrained=False, **kwargs):
+    if pretrained:
+        raise RuntimeError("pretrained weights are downloaded by the reference; unavailable offline")
+    kwargs.pop("drop_rate", None), kwargs.pop("drop_path_rate", None), kwargs.pop("drop_block_rate", None)
+    return MCTformerV2_DiG(patch_size=16, embed_dim=384, depth=12, num_heads=6, mlp_ratio=4, **kwargs)
+
+
+def create_model(name, pretrained=False, **kwargs):
+    """Stand-in for timm.create_model at the reference call site (model.py:117-124)."""
+    if name != "deit_small_MCTformerV2_DiG":
+        raise ValueError(f"unknown model {name}")
+    return deit_small_MCTformerV2_DiG(pretrained=pretrained, **kwargs)

@@ -1,0 +1,141 @@
+"""Thin tensor-level wrappers over the C-ABI kernels (dig_amd/_lib.py).  Activations are NHWC torch tensors
+([B,H,W,C], bf16 or fp32) living on the HIP device; torch is used only to own memory and streams."""
+import torch
+
+from . import _lib
+from ._lib import call, dtype_code
+
+GN_GROUPS = 8
+
+
+def _chk(t):
+    assert t.is_cuda and t.is_contiguous(), "dig_amd ops need contiguous HIP-device tensors"
+    return t
+
+
+def conv3x3(x0, w, bias, x1=None, aff=None, up2=False, want_stats=True, groups=GN_GROUPS):
+    """x0,x1: [B,h,w,C]; w packed [Cout,3,3,C0+C1]; returns (out [B,H,W,Cout], stats or None)."""
+    B, h, ww, C0 = x0.shape
+    H, W = (2 * h, 2 * ww) if up2 else (h, ww)
+    Cout = w.shape[0]
+    C1 = x1.shape[-1] if x1 is not None else 0
+    assert w.shape[-1] == C0 + C1, (w.shape, C0, C1)
+    out = torch.empty(B, H, W, Cout, dtype=x0.dtype, device=x0.device)
+    stats = None
+    if want_stats:
+        tiles = _lib.lib().dig_conv3x3_tiles(H, W)
+        stats = torch.empty(B, groups, tiles, 2, dtype=torch.float32, device=x0.device)
+    call("conv3x3", in0=_chk(x0), in1=_chk(x1) if x1 is not None else None, aff0=aff, w=_chk(w), bias=bias, out=out,
+         stats=stats, B=B, H=H, W=W, C0=C0, C1=C1, Cout=Cout, groups=groups, up2=int(up2), dtype=dtype_code(x0.dtype))
+    return out, stats
+
+
+def gn_finalize(stats, gamma, beta, hw, ss=None, ss_off=0, eps=1e-5):
+    """stats [B,G,tiles,2] -> aff [B,C,2].  ss: [B,ld] fp32 rows with (scale|shift) of this block at ss_off."""
+    B, G, tiles, _ = stats.shape
+    C = gamma.numel()
+    aff = torch.empty(B, C, 2, dtype=torch.float32, device=stats.device)
+    call("gn_finalize", stats=stats, gamma=gamma, beta=beta, ss=ss, aff=aff, B=B, C=C, groups=G, tiles=tiles, hw=hw,
+         ss_ld=ss.shape[1] if ss is not None else 0, ss_off=ss_off, eps=eps)
+    return aff
+
+
+def gn_silu_add(x, aff, res=None):
+    B, H, W, C = x.shape
+    out = torch.empty_like(x)
+    call("gn_silu_add", x=_chk(x), aff=aff, res=_chk(res) if res is not None else None, out=out, B=B, HW=H * W, C=C,
+         dtype=dtype_code(x.dtype))
+    return out
+
+
+def rmsnorm(x, g, res=None):
+    C = x.shape[-1]
+    out = torch.empty_like(x)
+    call("rmsnorm", x=_chk(x), g=g, res=_chk(res) if res is not None else None, out=out, rows=x.numel() // C, C=C,
+         dtype=dtype_code(x.dtype))
+    return out
+
+
+def gemm_nt(a0, b, c, M, N, K, *, dtype, a1=None, K0=0, lda0=None, lda1=0, ldb=None, ldc=None, bias=None, res=None, ldr=0,
+            gsrc=None, gaff=None, ldg=0, rows_per_img=0, alpha=1.0, gelu=False, out_f32=False, batch=1, z_inner=1,
+            sa=(0, 0), sa1=(0, 0), sb=(0, 0), sc=(0, 0), sr=(0, 0), unshuffle=None, nchw_hw=0):
+    """Raw access to dig_gemm_nt; strides are in elements.  a0/b/c may be tensors or (tensor, element_offset)."""
+
+    def ptr(x):
+        if x is None:
+            return None
+        if isinstance(x, tuple):
+            t, off = x
+            return t.data_ptr() + off * t.element_size()
+        return x.data_ptr()
+
+    kw = dict(a0=ptr(a0), a1=ptr(a1), b=ptr(b), c=ptr(c), bias=bias, res=ptr(res), gsrc=ptr(gsrc), gaff=gaff,
+              sa_o=sa[0], sa_i=sa[1], sa1_o=sa1[0], sa1_i=sa1[1], sb_o=sb[0], sb_i=sb[1], sc_o=sc[0], sc_i=sc[1],
+              sr_o=sr[0], sr_i=sr[1], M=M, N=N, K=K, K0=K0, lda0=lda0 if lda0 is not None else K, lda1=lda1,
+              ldb=ldb if ldb is not None else K, ldc=ldc if ldc is not None else N, ldr=ldr, ldg=ldg, batch=batch,
+              z_inner=z_inner, a_mode=0, unsh_Ho=0, unsh_Wo=0, unsh_C=0, c_mode=0, hw=0, rows_per_img=rows_per_img,
+              gelu=int(gelu), out_f32=int(out_f32), dtype=dtype_code(dtype), alpha=float(alpha))
+    if unshuffle is not None:
+        kw.update(a_mode=1, unsh_Ho=unshuffle[0], unsh_Wo=unshuffle[1], unsh_C=unshuffle[2])
+    if nchw_hw:
+        kw.update(c_mode=1, hw=nchw_hw)
+    call("gemm_nt", **kw)
+
+
+def linear_rows(x, w, bias=None, res=None, gelu=False, out_f32=False, x1=None, gsrc=None, gaff=None, rows_per_img=0):
+    """y[rows, N] = [x | x1] @ w^T (+bias, +silu(gn(gsrc)), gelu, +res).  x: [..., K0] contiguous; w: [N, K]."""
+    K0 = x.shape[-1]
+    K1 = x1.shape[-1] if x1 is not None else 0
+    N, K = w.shape
+    assert K == K0 + K1
+    M = x.numel() // K0
+    odt = torch.float32 if out_f32 else x.dtype
+    y = torch.empty(*x.shape[:-1], N, dtype=odt, device=x.device)
+    gemm_nt(_chk(x), _chk(w), y, M, N, K, dtype=x.dtype, a1=_chk(x1) if x1 is not None else None, K0=K0, lda0=K0, lda1=K1,
+            bias=bias, res=_chk(res) if res is not None else None, ldr=N, gsrc=_chk(gsrc) if gsrc is not None else None,
+            gaff=gaff, ldg=N, rows_per_img=rows_per_img, gelu=gelu, out_f32=out_f32)
+    return y
+
+
+def downsample_conv(x, w, bias):
+    """Pixel-unshuffle (2x2) + conv1x1; w packed [Cout, 4C] with K ordered (p1, p2, c)."""
+    B, H, W, C = x.shape
+    Ho, Wo = H // 2, W // 2
+    N = w.shape[0]
+    y = torch.empty(B, Ho, Wo, N, dtype=x.dtype, device=x.device)
+    gemm_nt(_chk(x), _chk(w), y, B * Ho * Wo, N, 4 * C, dtype=x.dtype, bias=bias, unshuffle=(Ho, Wo, C))
+    return y
+
+
+def row_softmax(s, out_dtype):
+    rows, n = s.numel() // s.shape[-1], s.shape[-1]
+    out = torch.empty(s.shape, dtype=out_dtype, device=s.device)
+    call("row_softmax", **{"in": _chk(s)}, out=out, rows=rows, n=n, in_f32=int(s.dtype == torch.float32), dtype=dtype_code(out_dtype))
+    return out
+
+
+def group_softmax32_(q, scale):
+    groups = q.shape[-1] // 32
+    call("group_softmax32", q=_chk(q), rows=q.numel() // q.shape[-1], groups=groups, dtype=dtype_code(q.dtype), scale=scale)
+    return q
+
+
+def nchw_to_nhwc(x, dtype):
+    B, C, H, W = x.shape
+    out = torch.empty(B, H, W, C, dtype=dtype, device=x.device)
+    call("nchw_f32_to_nhwc", **{"in": _chk(x.float())}, out=out, B=B, C=C, HW=H * W, dtype=dtype_code(dtype))
+    return out
+
+
+def nhwc_to_nchw_f32(x):
+    B, H, W, C = x.shape
+    out = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
+    call("nhwc_to_nchw_f32", **{"in": _chk(x)}, out=out, B=B, C=C, HW=H * W, dtype=dtype_code(x.dtype))
+    return out
+
+
+def bilinear_ac_into(x, out, c_off):
+    B, H, W, C = x.shape
+    _, Ctot, h, w = out.shape
+    call("bilinear_ac_concat", **{"in": _chk(x)}, out=out, B=B, H=H, W=W, C=C, h=h, w=w, Ctot=Ctot, c_off=c_off,
+         dtype=dtype_code(x.dtype))

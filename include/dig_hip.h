@@ -1,0 +1,245 @@
+/* dig_hip.h - C ABI of libdig_hip.so: the MI355X (gfx950) kernels under the DiG diffusion-guidance
+ * hot path.  The reference (yoon307/DiG) has no FFI layer - the path sits behind nn.Module calls that
+ * bottom out in ATen ops - so each entry point below names the reference call site(s) whose ATen op(s)
+ * it replaces ("ddp.py" = denoising_diffusion_pytorch/denoising_diffusion_pytorch.py).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing here allocates, frees or syncs;
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - return 0 on success, a negative DIG_E* code otherwise; dig_last_error() gives the message;
+ *   - activations are NHWC ("pixel-major"): [B][H][W][C], C contiguous; `dtype` selects the storage
+ *     type of activations and weights (DIG_BF16 or DIG_F32); accumulation/statistics are fp32;
+ *   - channel counts must be multiples of 8 (16-byte vectors); buffers must be 16-byte aligned.
+ */
+#ifndef DIG_HIP_H
+#define DIG_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIG_OK 0
+#define DIG_EINVAL (-1)  /* bad shape / argument */
+#define DIG_EALIGN (-2)  /* misaligned pointer or stride */
+#define DIG_ELAUNCH (-3) /* hipGetLastError() after launch */
+
+#define DIG_BF16 0
+#define DIG_F32 1
+
+int dig_version(void);
+const char* dig_last_error(void);
+
+/* ---- conv3x3, implicit GEMM on MFMA with an LDS-staged halo tile ------------------------------
+ * Replaces: Block.proj (ddp.py:154,159), Upsample's nearest x2 + conv (ddp.py:90-94), the last-stage
+ * 3x3 convs (ddp.py:349,366), torch.cat of skip connections (ddp.py:423,428,441) and - through the
+ * input prologue - GroupNorm + scale/shift + SiLU of the PREVIOUS Block (ddp.py:160-166).
+ *   in0/in1 : the two halves of a channel concat [B][Hi][Wi][C0|C1] (in1 may be NULL, C1 = 0);
+ *             with up2 != 0 the inputs are [B][H/2][W/2][C] and are read with nearest-x2 addressing.
+ *   aff0    : NULL, or [B][C0][2] fp32 (a, b): in0 is read as silu(a*x + b)  (GroupNorm-apply prologue)
+ *   w       : [Cout][3][3][C0+C1] (K-major repack of the OIHW weight), bias: [Cout] fp32
+ *   out     : [B][H][W][Cout] raw conv output (+bias)
+ *   stats   : NULL, or [B][groups][tiles][2] fp32 per-tile (sum, sumsq) of out over each GroupNorm group,
+ *             tiles = dig_conv3x3_tiles(H, W); reduced by dig_gn_finalize (deterministic, no atomics). */
+typedef struct {
+    const void* in0;
+    const void* in1;
+    const float* aff0;
+    const void* w;
+    const float* bias;
+    void* out;
+    float* stats;
+    int B, H, W, C0, C1, Cout, groups, up2, dtype;
+} dig_conv3x3_args;
+int dig_conv3x3_tiles(int H, int W);
+int dig_conv3x3(const dig_conv3x3_args* a, void* stream);
+
+/* ---- batched "NT" GEMM on MFMA: C[z][m][n] = epi( alpha * sum_k A[z][m][k] * Bm[z][n][k] ) -------
+ * Both operands are K-contiguous.  Replaces every conv1x1 / nn.Linear / einsum / matmul on the path:
+ * to_qkv, to_out, res_conv, Downsample's Rearrange + conv1x1 (ddp.py:102-106,180,209-213,250-251),
+ * final_conv (ddp.py:373), the time MLPs (ddp.py:172-175,318-320), Attend's two einsums
+ * (attend.py:102,111), LinearAttention's second einsum (ddp.py:231), and the ViT linears / patch embed.
+ *   A rows may be a concat of two tensors (a0: K0 columns, a1: K - K0 columns), or - a_mode 1 - the
+ *   2x2 pixel-unshuffle gather of an NHWC tensor (row m = output pixel, K = 4*C ordered (p1,p2,c)).
+ *   Batch index z = zo*z_inner + zi; every operand has an (outer, inner) element stride pair.
+ *   Epilogue, in order: *alpha, +bias[n], +silu(gaff[img][n][0]*gsrc[m][n] + gaff[img][n][1]) with
+ *   img = m / rows_per_img (GroupNorm-apply of a raw conv output fused into res_conv, ddp.py:160-166,194),
+ *   GELU(erf) if gelu, +res[m][n]; store as dtype (or fp32 if out_f32) row-major [m*ldc+n], or - c_mode 1 -
+ *   NCHW: out[(m/hw)*N*hw + n*hw + m%hw]. */
+typedef struct {
+    const void* a0;
+    const void* a1;
+    const void* b;
+    void* c;
+    const float* bias;
+    const void* res;
+    const void* gsrc;
+    const float* gaff;
+    long long sa_o, sa_i, sa1_o, sa1_i, sb_o, sb_i, sc_o, sc_i, sr_o, sr_i;
+    int M, N, K, K0, lda0, lda1, ldb, ldc, ldr, ldg;
+    int batch, z_inner;
+    int a_mode, unsh_Ho, unsh_Wo, unsh_C;
+    int c_mode, hw, rows_per_img;
+    int gelu, out_f32, dtype;
+    float alpha;
+} dig_gemm_args;
+int dig_gemm_nt(const dig_gemm_args* a, void* stream);
+
+/* ---- GroupNorm finalize: per-tile partials -> per-(image, channel) affine -----------------------
+ * Replaces nn.GroupNorm statistics (ddp.py:155,160) + `x*(scale+1)+shift` folding (ddp.py:162-164):
+ *   a[b][c] = rstd*gamma[c]*(1+scale[b][c]),  bb[b][c] = (beta[c]-mean*rstd*gamma[c])*(1+scale[b][c]) + shift[b][c]
+ * ss: NULL or rows [b*ss_ld + ss_off .. ] holding (scale[0..C), shift[0..C)) = the time-MLP output chunk. */
+typedef struct {
+    const float* stats;
+    const float* gamma;
+    const float* beta;
+    const float* ss;
+    float* aff;
+    int B, C, groups, tiles, hw, ss_ld, ss_off;
+    float eps;
+} dig_gn_finalize_args;
+int dig_gn_finalize(const dig_gn_finalize_args* a, void* stream);
+
+/* out = silu(a*x + b) [+ res]   (GroupNorm apply + SiLU + residual add; ddp.py:160-166,194 with identity res_conv) */
+typedef struct {
+    const void* x;
+    const float* aff;
+    const void* res;
+    void* out;
+    int B, HW, C, dtype;
+} dig_gn_silu_add_args;
+int dig_gn_silu_add(const dig_gn_silu_add_args* a, void* stream);
+
+/* RMSNorm over channels per pixel (ddp.py:108-114): out = x / max(||x||,1e-12) * g * sqrt(C) [+ res] */
+typedef struct {
+    const void* x;
+    const float* g;
+    const void* res;
+    void* out;
+    long long rows;
+    int C, dtype;
+} dig_rmsnorm_args;
+int dig_rmsnorm(const dig_rmsnorm_args* a, void* stream);
+
+/* softmax over each contiguous row; in fp32 [rows][n] -> out dtype [rows][n]  (attend.py:106; ddp.py:225 uses
+ * dig_row_max + dig_la_context instead).  in_f32: source rows are fp32 regardless of dtype. */
+typedef struct {
+    const void* in;
+    void* out;
+    long long rows;
+    int n, in_f32, dtype;
+} dig_row_softmax_args;
+int dig_row_softmax(const dig_row_softmax_args* a, void* stream);
+
+/* q.softmax(dim=-2) * scale of LinearAttention (ddp.py:224,227) on pixel-major q [rows][groups*32], in place */
+typedef struct {
+    void* q;
+    long long rows;
+    int groups, dtype;
+    float scale;
+} dig_group_softmax32_args;
+int dig_group_softmax32(const dig_group_softmax32_args* a, void* stream);
+
+/* LinearAttention context (ddp.py:225,229): k,v channel-major [32][n] slabs per (image, head); bh = b*heads + h.
+ *   dig_row_max:   kmax[r] = max_n k[r][n]
+ *   dig_la_context: per split s of n: part[bh][s][e][d] = sum_n v[e][n]*exp(k[d][n]-kmax[d]),  ksum[bh][s][d] = sum_n exp(..)
+ *   dig_la_finalize: ctxT[bh][e][d] = scale * sum_s part / sum_s ksum   (stored as dtype, the B operand of the out GEMM) */
+typedef struct {
+    const void* in;
+    float* out;
+    long long rows;        /* total rows reduced; row i lives at (i / group_rows)*group_stride + (i % group_rows)*n */
+    long long group_stride;
+    int group_rows, n, dtype;
+} dig_row_max_args;
+int dig_row_max(const dig_row_max_args* a, void* stream);
+typedef struct {
+    const void* k;
+    const void* v;
+    const float* kmax;
+    float* part;
+    float* ksum;
+    long long b_stride_k, h_stride_k, b_stride_v, h_stride_v; /* element strides of the (image, head) [32][n] slabs */
+    int B, heads, n, splits, dtype;
+} dig_la_context_args;
+int dig_la_context(const dig_la_context_args* a, void* stream);
+typedef struct {
+    const float* part;
+    const float* ksum;
+    void* ctxT;
+    int BH, splits, dtype;
+    float scale;
+} dig_la_finalize_args;
+int dig_la_finalize(const dig_la_finalize_args* a, void* stream);
+
+/* ---- stem: normalisation + q_sample + conv7x7 -------------------------------------------------------
+ * Replaces denormforDiff/normalize (model.py:499-508, ddp.py:82-83), extract + q_sample (ddp.py:452-455,
+ * 853-860) and init_conv (ddp.py:296,388).  img, noise: NCHW fp32 [B][3][H][W];
+ *   x0 = pre_scale[c]*img + pre_shift[c];  x_t = ca[t[b]]*x0 + cs[t[b]]*noise  (written to x_t, NCHW fp32, if non-NULL)
+ *   out = conv7x7(x_t) + bias  as NHWC dtype [B][H][W][Cout] (Cout % 16 == 0);  w: [49 taps][3][Cout] fp32. */
+typedef struct {
+    const float* img;
+    const float* noise;
+    const long long* t;
+    const float* sqrt_ac;
+    const float* sqrt_1mac;
+    const float* w;
+    const float* bias;
+    float* x_t;
+    void* out;
+    float pre_scale[3], pre_shift[3];
+    int B, H, W, Cout, dtype;
+} dig_stem_args;
+int dig_qsample_stem(const dig_stem_args* a, void* stream);
+
+/* out = post_scale[c]*(ca[t[b]]*x + sign*cs[t[b]]*y) + post_shift[c], NCHW fp32 (q_sample ddp.py:853-860 with sign=+1;
+ * predict_start_from_v ddp.py:630-634 with sign=-1, fused with unnormalize + normforCls, model.py:305-310,510-519) */
+typedef struct {
+    const float* x;
+    const float* y;
+    const long long* t;
+    const float* sqrt_ac;
+    const float* sqrt_1mac;
+    float* out;
+    float post_scale[3], post_shift[3];
+    float sign;
+    int B, HW;
+} dig_sched_axpby_args;
+int dig_sched_axpby(const dig_sched_axpby_args* a, void* stream);
+
+/* SinusoidalPosEmb (ddp.py:118-130): out[b][0..dim) fp32 = [sin(t*w_i), cos(t*w_i)] stored as dtype */
+typedef struct {
+    const long long* t;
+    void* out;
+    int B, dim, dtype;
+} dig_sinusoid_args;
+int dig_sinusoid(const dig_sinusoid_args* a, void* stream);
+
+/* elementwise activation on a flat buffer: act 0 = SiLU (ddp.py:173), 1 = GELU(erf) (ddp.py:319) */
+typedef struct {
+    const void* in;
+    void* out;
+    long long n;
+    int act, in_f32, out_f32, dtype;
+} dig_act_args;
+int dig_act(const dig_act_args* a, void* stream);
+
+/* bilinear resize, align_corners=True, NHWC dtype [B][H][W][C] -> NCHW fp32 slice of a [B][Ctot][h][w] tensor at
+ * channel offset c_off (F.interpolate ddp.py:418,434 fused with torch.cat(feat,1), model.py:313) */
+typedef struct {
+    const void* in;
+    float* out;
+    int B, H, W, C, h, w, Ctot, c_off, dtype;
+} dig_bilinear_ac_args;
+int dig_bilinear_ac_concat(const dig_bilinear_ac_args* a, void* stream);
+
+/* layout converters (test / boundary glue): NCHW fp32 <-> NHWC dtype */
+typedef struct {
+    const void* in;
+    void* out;
+    int B, C, HW, dtype;
+} dig_layout_args;
+int dig_nchw_f32_to_nhwc(const dig_layout_args* a, void* stream);
+int dig_nhwc_to_nchw_f32(const dig_layout_args* a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,146 @@
+"""GPU tier (-m gpu): U-Net blocks and the whole eval forward through the drop-in modules, against the CPU
+oracle and the golden vectors generated from the reference (tests/golden).
+Tolerances (max-abs):  fp32 storage 1e-3 (north-star), observed far lower;
+bf16 storage: the north-star's 2e-2 is stated next to the reference's own bf16-autocast envelope
+(2.2e-2 on v, up to 7.1e-2 on the guidance maps); we assert 2e-2 on v and 7.1e-2 on maps."""
+import numpy as np
+import pytest
+import torch
+
+import dig_oracle as O
+from dig_amd import diffusion as D
+from dig_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+torch.set_grad_enabled(False)
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def nhwc(x, dt):
+    return x.permute(0, 2, 3, 1).contiguous().to(device=DEV, dtype=dt)
+
+
+def nchw(y):
+    return y.float().permute(0, 3, 1, 2).cpu()
+
+
+def fill(m, tag):
+    for n, p in m.named_parameters():
+        p.copy_(synth.synth_param(tag + "." + n, p.shape))
+    return m
+
+
+def make_gd(dim, size, dt):
+    u = D.Unet(dim=dim, dim_mults=(1, 2, 4, 8), flash_attn=True)
+    synth.fill_state_dict(u, seed=0)
+    gd = D.GaussianDiffusion(u, image_size=size, timesteps=1000, sampling_timesteps=150).to(DEV).eval()
+    u.set_compute_dtype(dt)
+    return gd
+
+
+@pytest.mark.parametrize("dt,tl", [(torch.float32, 2e-4), (torch.bfloat16, 5e-2)])
+def test_blocks_vs_golden_ops(golden, dt, tl):
+    """ResnetBlock / LinearAttention / Attention / Attend on the ops.npz fixture (reference module outputs)."""
+    g = golden("ops")
+    x = synth.uniform_pm1("ops.x", (2, 32, 8, 12))
+    temb = synth.uniform_pm1("ops.temb", (2, 64))
+    xd = nhwc(x, dt)
+    # ResnetBlock with res_conv, and with identity residual
+    for name, cout in (("rb", 64), ("rb2", 32)):
+        m = fill(D.ResnetBlock(32, cout, time_emb_dim=64), name).to(DEV)
+        u = D.Unet(dim=16)  # only used for its packer helpers
+        P = {}
+        from dig_amd.diffusion import _conv1_pack, _conv3_pack
+        p = {"eps": 1e-5, "ss_off": 0}
+        p["w1"], p["b1"] = _conv3_pack(m.block1.proj, dt)
+        p["w2"], p["b2"] = _conv3_pack(m.block2.proj, dt)
+        p["g1"], p["be1"] = m.block1.norm.weight.float(), m.block1.norm.bias.float()
+        p["g2"], p["be2"] = m.block2.norm.weight.float(), m.block2.norm.bias.float()
+        p["res"] = _conv1_pack(m.res_conv, dt) if cout != 32 else None
+        st = torch.nn.functional.silu(temb).to(DEV)
+        ss = ops.linear_rows(st, m.mlp[1].weight.float().contiguous(), bias=m.mlp[1].bias.float())
+        y = D._resnet(p, xd, None, ss)
+        ref = T(g["resnet" if cout == 64 else "resnet_same"])
+        assert (nchw(y) - ref).abs().max() <= tl * max(1, ref.abs().max())
+    la = fill(D.LinearAttention(32), "la").to(DEV)
+    fa = fill(D.Attention(32, flash=True), "fa").to(DEV)
+    u = D.Unet(dim=16)
+    from dig_amd.diffusion import _pack_unet
+    # pack through the same code path as the full model
+    class _U:  # minimal shim exposing one attention module to the packer's attn() closure
+        pass
+    import types
+    def pack_attn(m):
+        d = {"full": isinstance(m, D.Attention), "heads": m.heads}
+        from dig_amd.diffusion import _conv1_pack
+        wqkv, _ = _conv1_pack(m.to_qkv, dt)
+        hid = m.heads * 32
+        d["g"] = m.norm.g.reshape(-1).float().contiguous()
+        if d["full"]:
+            d["wqk"], d["wv"] = wqkv[:2 * hid].contiguous(), wqkv[2 * hid:].contiguous()
+            d["wo"], d["bo"] = _conv1_pack(m.to_out, dt)
+        else:
+            d["wq"], d["wkv"] = wqkv[:hid].contiguous(), wqkv[hid:].contiguous()
+            d["wo"], d["bo"] = _conv1_pack(m.to_out[0], dt)
+            d["g2"] = m.to_out[1].g.reshape(-1).float().contiguous()
+        return d
+    y = D._linear_attention(pack_attn(la), xd)
+    ref = T(g["linattn"]) + x
+    assert (nchw(y) - ref).abs().max() <= tl * max(1, ref.abs().max())
+    y = D._full_attention(pack_attn(fa), xd)
+    ref = T(g["fullattn"]) + x
+    assert (nchw(y) - ref).abs().max() <= tl * max(1, ref.abs().max())
+    q, k, v = (synth.uniform_pm1("ops." + n, (2, 4, 24, 32)).to(device=DEV, dtype=dt) for n in "qkv")
+    o = D.Attend(flash=True)(q, k, v)
+    assert (o.float().cpu() - T(g["attend"])).abs().max() <= tl
+
+
+def _run_unet_case(golden, name, dim, H, W, B, dt):
+    g = golden(name)
+    gd = make_gd(dim, H, dt)
+    x0 = synth.synth_images(B, H, W, 1234).to(DEV)
+    nz = synth.synth_noise(B, H, W, 1235).to(DEV)
+    t = T(g["t"]).to(DEV)
+    x_t, v, feats = gd.p_losses(x0, t, noise=nz)
+    torch.cuda.synchronize()
+    d = {"x_t": float((x_t.cpu() - T(g["x_t"])).abs().max()), "v": float((v.cpu() - T(g["v"])).abs().max())}
+    for i, f in enumerate(feats):
+        assert tuple(f.shape) == g[f"feat{i}"].shape
+        d[f"feat{i}"] = float((f.cpu() - T(g[f"feat{i}"])).abs().max())
+    print(name, dt, d)
+    return d
+
+
+@pytest.mark.parametrize("case", [("unet_tiny32", 16, 32, 32, 2), ("unet_rect_48x32", 16, 48, 32, 1), ("unet128_t100", 64, 128, 128, 1)])
+def test_unet_fp32_vs_reference_golden(golden, case):
+    d = _run_unet_case(golden, *case, torch.float32)
+    assert d["x_t"] <= 1e-6
+    assert max(d.values()) <= 1e-3, d
+
+
+@pytest.mark.parametrize("case", [("unet_tiny32", 16, 32, 32, 2), ("unet128_t100", 64, 128, 128, 1)])
+def test_unet_bf16_vs_reference_golden(golden, case):
+    d = _run_unet_case(golden, *case, torch.bfloat16)
+    assert d["v"] <= 2e-2, d
+    assert max(d[f"feat{i}"] for i in range(5)) <= 7.1e-2, d
+
+
+def test_unet_forward_api_and_determinism():
+    """Unet.forward(x, t) (ddp.py:379-448) equals p_losses' model call, and two runs are bitwise identical
+    (no atomics anywhere on the path)."""
+    gd = make_gd(16, 32, torch.bfloat16)
+    x0 = synth.synth_images(3, 32, 32, 7).to(DEV)
+    nz = synth.synth_noise(3, 32, 32, 8).to(DEV)
+    t = torch.tensor([0, 4, 100], device=DEV)
+    x_t, v, feats = gd.p_losses(x0, t, noise=nz)
+    v2, feats2 = gd.model(x_t, t)
+    assert torch.equal(v, v2) and all(torch.equal(a, b) for a, b in zip(feats, feats2))
+    assert torch.equal(gd.q_sample(x0, t, nz), x_t)
+    # batch invariance: image 1 alone gives the same bits as inside the batch of 3
+    _, v1, f1 = gd.p_losses(x0[1:2], t[1:2], noise=nz[1:2])
+    assert torch.equal(v1, v[1:2]) and all(torch.equal(a, b[1:2]) for a, b in zip(f1, feats))
+    assert len(gd.state_dict()) == 287
