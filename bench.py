@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""bench.py - guidance maps/sec of the DiG diffusion-guidance forward on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic images already resident in HBM:
+q_sample at t=100 -> Unet eval forward -> five guidance maps concatenated to [B,1024,H/16,W/16]
+(BASELINE.json configs[1]: batch 32, 256x256, bf16 storage / fp32 accumulate).  With N > 1 ranks (one process per
+GPU, launched by torch.distributed.run) every rank runs its own batch of 32 (weak scaling) and the step ends with
+the single RCCL all-gather of the guidance maps that the north-star names.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     : the dominant kernel (conv3x3 implicit GEMM) - algorithmic FLOPs / HIP-event time, vs 2.5 PFLOP/s
+  cpu_baseline : the CPU oracle (oracle/dig_oracle.py, a port of the reference's PyTorch graph) timed on this box's
+                 host cores on a bounded sample (B=1 images at the same resolution), rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_MAP = {256: 234.94, 224: 179.58, 128: 58.43}
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--t", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
+    ap.add_argument("--profile-kernels", action="store_true", help="per-kernel-class HIP-event breakdown (stderr)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from dig_amd import ops, synth
+    from dig_amd.diffusion import GaussianDiffusion, Unet
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    torch.set_grad_enabled(False)
+
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    B, S = args.batch, args.size
+    unet = Unet(dim=64, dim_mults=(1, 2, 4, 8), flash_attn=True)
+    synth.fill_state_dict(unet, seed=0)
+    gd = GaussianDiffusion(unet, image_size=S, timesteps=1000, sampling_timesteps=150).eval()
+    cpu_sd = {k: v.clone() for k, v in gd.state_dict().items()} if rank == 0 else None
+    gd = gd.to(dev)
+    unet.set_compute_dtype(dt)
+    # synthetic inputs, resident in HBM before the timed region; each rank gets its own images
+    x0 = synth.synth_images(B, S, S, seed=1234 + rank * B).to(dev)
+    nz = synth.synth_noise(B, S, S, seed=1235 + rank * B).to(dev)
+    t = torch.full((B,), args.t, dtype=torch.long, device=dev)
+    h = S // 16
+    gathered = torch.empty(world * B, 1024, h, h, dtype=torch.float32, device=dev) if world > 1 else None
+
+    # ---- HIP-event instrumentation of the dominant kernel (conv3x3) on the launch stream
+    conv_log = []  # (class, flops, start_event, end_event)
+    orig_conv = ops.conv3x3
+    state = {"on": False}
+
+    def conv_timed(x0_, w, bias, x1=None, aff=None, up2=False, want_stats=True, groups=8):
+        if not state["on"]:
+            return orig_conv(x0_, w, bias, x1=x1, aff=aff, up2=up2, want_stats=want_stats, groups=groups)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_conv(x0_, w, bias, x1=x1, aff=aff, up2=up2, want_stats=want_stats, groups=groups)
+        e1.record()
+        Bc, Hc, Wc, Co = out[0].shape
+        cls = "conv3x3_bn128" if Co % 128 == 0 else ("conv3x3_bn64" if Co > 32 else "conv3x3_bn32")
+        conv_log.append((cls, 2.0 * Bc * Hc * Wc * Co * w.shape[-1] * 9, e0, e1))
+        return out
+
+    ops.conv3x3 = conv_timed
+
+    def step():
+        x_t, v, feats = gd.p_losses(x0, t, noise=nz)
+        maps = unet._last_maps  # [B,1024,h,h] fp32, == torch.cat(feats, 1) (model.py:313)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, maps)
+        return v, maps
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    sync_all()
+    state["on"] = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    state["on"] = False
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    maps_per_s = world * B / (elapsed / args.steps)
+
+    # ---- roofline of the dominant kernel class
+    per_cls = {}
+    for cls, fl, e0, e1 in conv_log:
+        d = per_cls.setdefault(cls, [0.0, 0.0, 0])
+        d[0] += fl
+        d[1] += e0.elapsed_time(e1) * 1e-3
+        d[2] += 1
+    dom = max(per_cls, key=lambda k: per_cls[k][1]) if per_cls else None
+    peak = PEAK_BF16_TFLOPS if dt == torch.bfloat16 else PEAK_F32_TFLOPS
+    roof = None
+    if dom:
+        fl, sec, n = per_cls[dom]
+        ach = fl / sec / 1e12
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": None, "launches": n, "avg_launch_ms": round(1e3 * sec / n, 4),
+                "flops_per_launch_avg": fl / n,
+                "classes": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(1e3 * v[1] / args.steps, 3),
+                                "launches_per_step": v[2] // args.steps} for k, v in per_cls.items()}}
+    gflop = GFLOP_PER_MAP.get(S)
+    whole = {"tflops": round(maps_per_s / world * gflop / 1e3, 2), "frac_of_mfma_peak": round(maps_per_s / world * gflop / 1e3 / peak, 4)} if gflop else None
+
+    # ---- CPU baseline: the oracle (a port of the reference graph) on the host cores, bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import dig_oracle as O
+        cores = min(16, os.cpu_count() or 1)
+        torch.set_num_threads(cores)
+        cx, cn, ct = x0[:1].cpu(), nz[:1].cpu(), t[:1].cpu()
+        O.p_losses_eval(cpu_sd, cx, ct, cn)  # warm-up
+        n_done, c0 = 0, time.perf_counter()
+        while n_done < 10 and time.perf_counter() - c0 < 15.0:
+            O.p_losses_eval(cpu_sd, cx, ct, cn)
+            n_done += 1
+        csec = (time.perf_counter() - c0) / n_done
+        cpu = {"value": round(1.0 / csec, 3), "unit": "maps/s", "cores": cores, "kind": "port",
+               "sample": f"{n_done} x (B=1, {S}x{S}, t={args.t}) fp32 forwards of oracle/dig_oracle.py (torch CPU ops), {csec*1e3:.0f} ms each"}
+
+    if rank == 0:
+        out = {"metric": "guidance maps/sec (Unet fwd 256x256, bs32)", "value": round(maps_per_s, 2), "unit": "maps/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": f"BASELINE.json configs[1]: batch-{B} Unet(dim=64, mults 1,2,4,8) guidance extraction at {S}x{S}, "
+                                      f"t={args.t}, q_sample + Unet eval forward + 5 guidance maps -> [B,1024,{h},{h}]",
+                          "per_gpu_batch": B, "global_batch": world * B, "image": S, "parallelism": f"dp{world}",
+                          "collective": "all_gather_into_tensor(maps)" if world > 1 else "none"},
+               "whole_forward": whole, "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

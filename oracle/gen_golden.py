@@ -32,6 +32,7 @@ warnings.filterwarnings("ignore")
 torch.set_grad_enabled(False)
 GOLD = os.path.join(ROOT, "tests", "golden")
 MANIFEST = {}
+ENVELOPE = {}  # reference's OWN bf16-autocast error vs its fp32 output, per case (context for the bf16 tolerance)
 
 
 def maxabs(a, b):
@@ -84,6 +85,14 @@ def case_unet(ddp, name, dim, H, W, B, tvals, keep_inter=False):
     _, v2, _ = gd2.p_losses(x0, t, noise=noise.clone())
     d["sdpa_vs_math"] = maxabs(v, v2)
     record(name, **d)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        _, vb, fb = gd2.p_losses(x0, t, noise=noise.clone())
+    env = {"v": maxabs(v, vb.float()), "v_absmax": float(v.abs().max())}
+    for i, (a, b) in enumerate(zip(feats, fb)):
+        env[f"feat{i}"] = maxabs(a, b.float())
+        env[f"feat{i}_absmax"] = float(a.abs().max())
+    ENVELOPE[name] = env
+    print(f"[{name}] reference bf16-autocast envelope: " + "  ".join(f"{k}={x:.3e}" for k, x in env.items()))
     arrays = dict(t=t.numpy(), x_t=x_t, v=v, **{f"feat{i}": f for i, f in enumerate(feats)})
     if keep_inter:
         for k in ("temb", "downs.0.attn", "downs.3.out", "mid", "ups.3.out"):
@@ -217,7 +226,9 @@ def main():
     case_cam(mct, "cam224_c80", 80, 224, 224, 1)
     with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
         json.dump({"generator": "oracle/gen_golden.py", "torch": torch.__version__,
-                   "what": "max-abs |reference - oracle| per output, fp32 CPU", "cases": MANIFEST}, f, indent=1)
+                   "what": "max-abs |reference - oracle| per output, fp32 CPU", "cases": MANIFEST,
+                   "bf16_envelope_what": "max-abs |reference fp32 - reference under torch.autocast(cpu, bfloat16)| and max|reference fp32|",
+                   "bf16_envelope": ENVELOPE}, f, indent=1)
 
 
 if __name__ == "__main__":
