@@ -1,73 +1,107 @@
 // Stem: input normalisation + q_sample + conv7x7 (3 -> Cout, pad 3) in one kernel (gfx950).
-// The noised image x_t is formed in registers from the NCHW fp32 image and noise while the 22x22x3 halo tile
-// is staged in LDS, so normalisation and q_sample never touch HBM on their own.  K = 147 is too ragged for a
-// clean MFMA mapping and the layer is 0.5 % of the network's FLOPs, so this is an fp32 VALU direct convolution:
-// one thread per output pixel, 16 output channels per pass, weights broadcast from LDS as float4.
+//
+// The noised image x_t = ca[t]*pre(img) + cs[t]*noise is formed in registers from the NCHW fp32 inputs while the
+// (8+6)x(16+6)x3 halo tile is staged in LDS, so normalisation and q_sample never touch HBM on their own (x_t is
+// also written out once, NCHW fp32, because p_losses returns it).  The convolution is an implicit GEMM on MFMA:
+// each 256-thread block owns an 8x16-pixel tile, builds the [128 pixels][K] im2col panel in LDS with
+// K = 7*7*3 = 147 zero-padded to 160 (k = (ky*7+kx)*3 + c), keeps the [Cout][K] weight panel beside it, and runs
+// 10 16-deep MFMA steps per 32x32 output tile.  Output NHWC in the storage type T (bf16 or f32).
 #include "common.hpp"
 
 namespace {
 
-constexpr int ST = 16, SH = ST + 6;  // 16x16 tile, 22x22 halo
+constexpr int TH = 8, TW = 16;            // output tile
+constexpr int HH = TH + 6, HW_ = TW + 6;  // halo 14 x 22
+constexpr int KPAD = 160, KROW = KPAD + 8;
 
 template <typename T> __global__ __launch_bounds__(256) void stem_kernel(dig_stem_args a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* halo = sm;                 // [3][22][23]
-    float* wl = sm + 3 * SH * (SH + 1);  // [147][Cout]
-    const int tid = threadIdx.x;
-    const int tiles_x = (a.W + ST - 1) / ST, tiles_y = (a.H + ST - 1) / ST;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* halo = reinterpret_cast<float*>(smem);                    // [3][14][23] fp32
+    T* Ap = reinterpret_cast<T*>(smem + 3 * HH * (HW_ + 1) * 4 + 8); // [128][KROW]  (offset keeps 16-B alignment: 3864+8)
+    T* Wp = Ap + 128 * KROW;                                         // [Cout][KROW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
     const int b = blockIdx.x / (tiles_x * tiles_y), tile = blockIdx.x % (tiles_x * tiles_y);
-    const int ty0 = (tile / tiles_x) * ST, tx0 = (tile % tiles_x) * ST;
+    const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
     const long long t = a.t[b];
     const float ca = a.sqrt_ac[t], cs = a.sqrt_1mac[t];
     const size_t HW = (size_t)a.H * a.W;
-    for (int i = tid; i < 3 * SH * SH; i += 256) {
-        const int c = i / (SH * SH), rem = i % (SH * SH), hy = rem / SH, hx = rem % SH;
+    for (int i = tid; i < 3 * HH * HW_; i += 256) {
+        const int c = i / (HH * HW_), rem = i % (HH * HW_), hy = rem / HW_, hx = rem % HW_;
         const int Y = ty0 + hy - 3, X = tx0 + hx - 3;
         float v = 0.f;
         if (Y >= 0 && Y < a.H && X >= 0 && X < a.W) {
             const size_t idx = ((size_t)b * 3 + c) * HW + (size_t)Y * a.W + X;
             const float x0 = a.pre_scale[c] * a.img[idx] + a.pre_shift[c];
             v = ca * x0 + cs * a.noise[idx];
-            if (a.x_t && hy >= 3 && hy < 3 + ST && hx >= 3 && hx < 3 + ST) a.x_t[idx] = v;
+            if (a.x_t && hy >= 3 && hy < 3 + TH && hx >= 3 && hx < 3 + TW) a.x_t[idx] = v;
         }
-        halo[(c * SH + hy) * (SH + 1) + hx] = v;
+        halo[(c * HH + hy) * (HW_ + 1) + hx] = v;
     }
-    for (int i = tid; i < 147 * a.Cout; i += 256) wl[i] = a.w[i];
+    // weight panel: w is [147][Cout] fp32 (tap-major); transpose into [Cout][KROW] T with zero K padding
+    for (int i = tid; i < a.Cout * KPAD; i += 256) {
+        const int n = i / KPAD, k = i - n * KPAD;
+        Wp[n * KROW + k] = from_f32<T>(k < 147 ? a.w[k * a.Cout + n] : 0.f);
+    }
     __syncthreads();
-    const int py = tid >> 4, px = tid & 15;
-    const int Y = ty0 + py, X = tx0 + px;
-    const bool ok = Y < a.H && X < a.W;
-    T* out = (T*)a.out + (((size_t)b * a.H + Y) * a.W + X) * a.Cout;
-    for (int n0 = 0; n0 < a.Cout; n0 += 16) {
-        float acc[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++) acc[j] = a.bias[n0 + j];
-        for (int ky = 0; ky < 7; ky++)
-            for (int kx = 0; kx < 7; kx++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    const float x = halo[(c * SH + py + ky) * (SH + 1) + px + kx];
-                    const f32x4* w4 = reinterpret_cast<const f32x4*>(wl + ((ky * 7 + kx) * 3 + c) * a.Cout + n0);
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const f32x4 w = w4[q];
-                        acc[q * 4 + 0] += x * w[0];
-                        acc[q * 4 + 1] += x * w[1];
-                        acc[q * 4 + 2] += x * w[2];
-                        acc[q * 4 + 3] += x * w[3];
-                    }
-                }
-        if (ok) {
-            Frag<T> f0, f1;
+    // im2col panel: 2 threads per pixel, each builds 10 of the 20 8-element vectors of its row
+    {
+        const int pix = tid >> 1, half = tid & 1;
+        const int py = pix / TW, px = pix % TW;
+#pragma unroll 2
+        for (int v = 0; v < 10; v++) {
+            const int k0 = (half * 10 + v) * 8;
+            Frag<T> f;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                frag_set<T>(f0, j, acc[j]);
-                frag_set<T>(f1, j, acc[8 + j]);
+                const int k = k0 + j;
+                float x = 0.f;
+                if (k < 147) {
+                    const int tap = k / 3, c = k - tap * 3, ky = tap / 7, kx = tap - ky * 7;
+                    x = halo[(c * HH + py + ky) * (HW_ + 1) + px + kx];
+                }
+                frag_set<T>(f, j, x);
             }
-            frag_store<T>(f0, out + n0);
-            frag_store<T>(f1, out + n0 + 8);
+            frag_store<T>(f, Ap + pix * KROW + k0);
         }
     }
+    __syncthreads();
+    // MFMA: wave w owns pixels 32w..32w+31 (tile rows 2w, 2w+1) x all Cout, 32 channels at a time
+    for (int n0 = 0; n0 < a.Cout; n0 += 32) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[e] = 0.f;
+        const bool nv = n0 + r < a.Cout;
+#pragma unroll
+        for (int kk = 0; kk < KPAD / 16; kk++) {
+            Frag<T> fa, fb;
+            frag_load<T>(fa, Ap + (wave * 32 + r) * KROW + kk * 16 + hf * 8);
+            if (nv) frag_load<T>(fb, Wp + (n0 + r) * KROW + kk * 16 + hf * 8);
+            else frag_zero<T>(fb);
+            mma16<T>(acc, fa, fb);
+        }
+        const float bias = nv ? a.bias[n0 + r] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int pix = wave * 32 + acc_row(e, lane);
+            const int Y = ty0 + pix / TW, X = tx0 + pix % TW;
+            if (nv && Y < a.H && X < a.W)
+                ((T*)a.out)[(((size_t)b * a.H + Y) * a.W + X) * a.Cout + n0 + r] = from_f32<T>(acc[e] + bias);
+        }
+    }
+}
+
+template <typename T> size_t stem_lds(int Cout) { return 3 * HH * (HW_ + 1) * 4 + 8 + (size_t)(128 + Cout) * KROW * sizeof(T); }
+
+template <typename T> int launch(const dig_stem_args* a, hipStream_t stream) {
+    const size_t lds = stem_lds<T>(a->Cout);
+    DIG_CHECK(lds <= 160 * 1024, DIG_EINVAL, "qsample_stem: Cout=%d needs %zu B of LDS", a->Cout, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)stem_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "qsample_stem: cannot raise dynamic LDS: %s", hipGetErrorString(e));
+    const int tiles = cdiv(a->W, TW) * cdiv(a->H, TH);
+    hipLaunchKernelGGL(stem_kernel<T>, dim3(a->B * tiles), dim3(256), lds, stream, *a);
+    DIG_LAUNCH_CHECK("qsample_stem");
+    return DIG_OK;
 }
 
 }  // namespace
@@ -75,16 +109,8 @@ template <typename T> __global__ __launch_bounds__(256) void stem_kernel(dig_ste
 extern "C" int dig_qsample_stem(const dig_stem_args* a, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DIG_CHECK(a && a->img && a->noise && a->t && a->sqrt_ac && a->sqrt_1mac && a->w && a->bias && a->out, DIG_EINVAL, "qsample_stem: null pointer");
-    DIG_CHECK(a->B > 0 && a->H > 0 && a->W > 0 && a->Cout > 0 && a->Cout % 16 == 0 && a->Cout <= 128, DIG_EINVAL, "qsample_stem: bad shape (Cout=%d)", a->Cout);
-    const size_t lds = (size_t)(3 * SH * (SH + 1) + 147 * a->Cout) * sizeof(float);
-    const int tiles = cdiv(a->W, ST) * cdiv(a->H, ST);
-    if (a->dtype == DIG_BF16) {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)stem_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(stem_kernel<bf16>, dim3(a->B * tiles), dim3(256), lds, stream, *a);
-    } else {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)stem_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(stem_kernel<float>, dim3(a->B * tiles), dim3(256), lds, stream, *a);
-    }
-    DIG_LAUNCH_CHECK("qsample_stem");
-    return DIG_OK;
+    DIG_CHECK(a->B > 0 && a->H > 0 && a->W > 0 && a->Cout > 0 && a->Cout % 8 == 0, DIG_EINVAL, "qsample_stem: bad shape (Cout=%d)", a->Cout);
+    if (a->dtype == DIG_BF16) return launch<bf16>(a, stream);
+    if (a->dtype == DIG_F32) return launch<float>(a, stream);
+    DIG_CHECK(false, DIG_EINVAL, "qsample_stem: unknown dtype %d", a->dtype);
 }
