@@ -39,6 +39,7 @@ template <typename T> struct Params {
     const float* bias;
     T* out;
     float* stats;
+    long long bstride0;
     int B, H, W, Cout, groups, up2, tiles_x, tiles_y;
 };
 
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_kernel(Params<T> p) {
             const bool ok = chv && Y >= 0 && Y < p.H && X >= 0 && X < p.W;
             if (ok) {
                 const int sy = p.up2 ? Y >> 1 : Y, sx = p.up2 ? X >> 1 : X;
-                frag_load<T>(f, src + (((size_t)b * Hs + sy) * Ws + sx) * Cp + ch);
+                frag_load<T>(f, src + (size_t)b * (piece ? (size_t)Hs * Ws * Cp : (size_t)p.bstride0) + ((size_t)sy * Ws + sx) * Cp + ch);
                 if (pro) {
 #pragma unroll
                     for (int j = 0; j < 8; j++) frag_set<T>(f, j, silu_f(pa[j] * frag_get<T>(f, j) + pb[j]));
@@ -229,6 +230,7 @@ int launch(const dig_conv3x3_args* a, hipStream_t stream) {
     p.bias = a->bias;
     p.out = (T*)a->out;
     p.stats = a->stats;
+    p.bstride0 = a->in0_bstride > 0 ? a->in0_bstride : (long long)(a->up2 ? (a->H / 2) * (a->W / 2) : a->H * a->W) * a->C0;
     p.B = a->B; p.H = a->H; p.W = a->W; p.Cout = a->Cout; p.groups = a->groups; p.up2 = a->up2;
     p.tiles_x = cdiv(a->W, TILE);
     p.tiles_y = cdiv(a->H, TILE);

@@ -1,0 +1,325 @@
+// MCTformer class-token attention -> CAM path (gfx950), fp32 throughout so that the argmax label maps match the
+// reference: patch im2row, LayerNorm, multi-head attention with on-the-fly head-mean / layer-sum rollout (the
+// 12 x [B,6,N,N] probability tensors of the reference are never materialised), bicubic pos-embed resize,
+// CAM aggregation, flip-TTA + bilinear upsample + max_norm, and the argmax label map.
+// The linears of the ViT run on the f32 MFMA GEMM (gemm.hip); the pieces here are small and HBM/LDS bound.
+#include "common.hpp"
+
+namespace {
+
+// ---- patch im2row: one thread per (patch row, c, ky) copies ps contiguous pixels --------------------------
+__global__ void patchify_kernel(dig_patchify_args a) {
+    const int hp = a.H / a.ps, wp = a.W / a.ps, K = 3 * a.ps * a.ps;
+    const size_t total = (size_t)a.B * hp * wp * 3 * a.ps * a.ps;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const size_t row = i / K;
+        const int kx = k % a.ps, ky = (k / a.ps) % a.ps, c = k / (a.ps * a.ps);
+        const int px = (int)(row % wp), py = (int)((row / wp) % hp), b = (int)(row / ((size_t)wp * hp));
+        a.rows[i] = a.img[(((size_t)b * 3 + c) * a.H + py * a.ps + ky) * a.W + px * a.ps + kx];
+    }
+}
+
+// ---- LayerNorm: one wave per row (two-pass mean/variance in fp32) ------------------------------------------
+__global__ void layernorm_kernel(dig_layernorm_args a) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const float* x = a.x + row * a.D;
+    float s = 0.f;
+    for (int i = lane; i < a.D; i += 64) s += x[i];
+    const float mean = wave_sum(s) / (float)a.D;
+    float v = 0.f;
+    for (int i = lane; i < a.D; i += 64) {
+        const float d = x[i] - mean;
+        v += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(v) / (float)a.D + a.eps);
+    float* o = a.out + row * a.D;
+    for (int i = lane; i < a.D; i += 64) o[i] = (x[i] - mean) * rstd * a.gamma[i] + a.beta[i];
+}
+
+// ---- attention with rollout: block = (query tile of TQ rows, image); loops over heads ----------------------
+constexpr int TQ = 8;
+template <int DH> __global__ __launch_bounds__(256) void vit_attn_kernel(dig_vit_attn_args a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int N = a.N, Np = (N + 3) & ~3;
+    float* Ps = sm;                 // [TQ][Np] probabilities of the current head
+    float* Pacc = Ps + TQ * Np;     // [TQ][Np] sum over heads
+    float* Qs = Pacc + TQ * Np;     // [TQ][DH]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, q0 = blockIdx.x * TQ;
+    const int D3 = 3 * a.heads * DH, Dm = a.heads * DH;
+    const float* qkv = a.qkv + (size_t)b * N * D3;
+    const float scale = rsqrtf((float)DH);
+    for (int i = tid; i < TQ * Np; i += 256) Pacc[i] = 0.f;
+    for (int h = 0; h < a.heads; h++) {
+        __syncthreads();
+        for (int i = tid; i < TQ * DH; i += 256) {
+            const int qi = i / DH, d = i - qi * DH;
+            Qs[i] = (q0 + qi < N) ? qkv[(size_t)(q0 + qi) * D3 + h * DH + d] : 0.f;
+        }
+        __syncthreads();
+        // scores: each thread owns keys j = tid, tid+256, ...
+        for (int j = tid; j < N; j += 256) {
+            const f32x4* kp = reinterpret_cast<const f32x4*>(qkv + (size_t)j * D3 + Dm + h * DH);
+            float accq[TQ];
+#pragma unroll
+            for (int i = 0; i < TQ; i++) accq[i] = 0.f;
+#pragma unroll
+            for (int d4 = 0; d4 < DH / 4; d4++) {
+                const f32x4 kv = kp[d4];
+#pragma unroll
+                for (int i = 0; i < TQ; i++) {
+                    const f32x4 qv = *reinterpret_cast<const f32x4*>(Qs + i * DH + d4 * 4);
+                    accq[i] += qv[0] * kv[0] + qv[1] * kv[1] + qv[2] * kv[2] + qv[3] * kv[3];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TQ; i++) Ps[i * Np + j] = accq[i] * scale;
+        }
+        __syncthreads();
+        // softmax: 32 lanes per query row
+        {
+            const int qi = tid >> 5, l = tid & 31;
+            float* row = Ps + qi * Np;
+            float m = -INFINITY;
+            for (int j = l; j < N; j += 32) m = fmaxf(m, row[j]);
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            float s = 0.f;
+            for (int j = l; j < N; j += 32) {
+                const float e = expf(row[j] - m);
+                row[j] = e;
+                s += e;
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            const float inv = 1.0f / s;
+            float* arow = Pacc + qi * Np;
+            for (int j = l; j < N; j += 32) {
+                const float pv = row[j] * inv;
+                row[j] = pv;
+                arow[j] += pv;
+            }
+        }
+        __syncthreads();
+        // O = P V : thread = (query row, 2 output dims)
+        {
+            constexpr int TPR = DH / 2;            // threads per row
+            const int qi = tid / TPR, d2 = (tid % TPR) * 2;
+            if (qi < TQ && q0 + qi < N) {
+                const float* prow = Ps + qi * Np;
+                const float* vp = qkv + 2 * Dm + h * DH + d2;
+                float o0 = 0.f, o1 = 0.f;
+                for (int j = 0; j < N; j++) {
+                    const f32x2 vv = *reinterpret_cast<const f32x2*>(vp + (size_t)j * D3);
+                    o0 += prow[j] * vv[0];
+                    o1 += prow[j] * vv[1];
+                }
+                float* op = a.out + ((size_t)b * N + q0 + qi) * Dm + h * DH + d2;
+                op[0] = o0;
+                op[1] = o1;
+            }
+        }
+    }
+    __syncthreads();
+    const float nh = (float)a.heads;
+    for (int i = tid; i < TQ * N; i += 256) {
+        const int qi = i / N, j = i - qi * N;
+        const int q = q0 + qi;
+        if (q >= N) continue;
+        const float mean = Pacc[qi * Np + j] / nh;  // torch.mean over heads (mctformer.py:303)
+        a.acc_all[((size_t)b * N + q) * N + j] += mean;
+        if (a.acc_cls && q < a.ncls) a.acc_cls[((size_t)b * a.ncls + q) * N + j] += mean;
+    }
+}
+
+// ---- bicubic resize of the pos-embed grid -----------------------------------------------------------------
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+__global__ void bicubic_pos_kernel(dig_bicubic_pos_args a) {
+    const float A = -0.75f;
+    const size_t total = (size_t)a.ho * a.wo * a.D;
+    const float rh = a.rscale_h, rw = a.rscale_w;  // area_pixel_compute_scale with a given scale factor
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % a.D);
+        const int ox = (int)((i / a.D) % a.wo), oy = (int)(i / ((size_t)a.D * a.wo));
+        const float sy = rh * (oy + 0.5f) - 0.5f, sx = rw * (ox + 0.5f) - 0.5f;
+        const int iy = (int)floorf(sy), ix = (int)floorf(sx);
+        const float ty = sy - iy, tx = sx - ix;
+        float wy[4] = {cubic2(ty + 1.f, A), cubic1(ty, A), cubic1(1.f - ty, A), cubic2(2.f - ty, A)};
+        float wx[4] = {cubic2(tx + 1.f, A), cubic1(tx, A), cubic1(1.f - tx, A), cubic2(2.f - tx, A)};
+        float acc = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int yy = min(max(iy - 1 + m, 0), a.g - 1);
+            float rowv = 0.f;
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+                const int xx = min(max(ix - 1 + n, 0), a.g - 1);
+                rowv += a.in[((size_t)yy * a.g + xx) * a.D + d] * wx[n];
+            }
+            acc += rowv * wy[m];
+        }
+        a.out[i] = acc;
+    }
+}
+
+// ---- CAM aggregation: one block per (b, c) -----------------------------------------------------------------
+__global__ void cam_fuse_kernel(dig_cam_fuse_args a) {
+    extern __shared__ __attribute__((aligned(16))) float camsm[];  // [P]
+    const int b = blockIdx.x / a.C, c = blockIdx.x % a.C;
+    const int N = a.C + a.P;
+    for (int p = threadIdx.x; p < a.P; p += blockDim.x) {
+        const float mt = a.acc_cls[((size_t)b * a.C + c) * N + a.C + p];
+        const float hv = fmaxf(a.head[((size_t)b * a.P + p) * a.C + c], 0.f);
+        const float cm = mt * hv;
+        camsm[p] = cm;
+        a.mtatt[((size_t)b * a.C + c) * a.P + p] = mt;
+        a.cams[((size_t)b * a.C + c) * a.P + p] = cm;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < a.P; p += blockDim.x) {
+        const float* arow = a.acc_all + ((size_t)b * N + a.C + p) * N + a.C;
+        float s = 0.f;
+        for (int q = 0; q < a.P; q++) s += arow[q] * camsm[q];
+        a.rcams[((size_t)b * a.C + c) * a.P + p] = s;
+    }
+}
+
+// ---- flip-TTA + bilinear (align_corners=False) + max_norm: one block per (b, c) ----------------------------
+__device__ __forceinline__ float bilin(const float* m, int hp, int wp, float sh, float sw, int y, int x) {
+    float fy = sh * (y + 0.5f) - 0.5f, fx = sw * (x + 0.5f) - 0.5f;
+    fy = fy < 0.f ? 0.f : fy;
+    fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < hp - 1 ? 1 : 0), x1 = x0 + (x0 < wp - 1 ? 1 : 0);
+    const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    return hy * (hx * m[y0 * wp + x0] + lx * m[y0 * wp + x1]) + ly * (hx * m[y1 * wp + x0] + lx * m[y1 * wp + x1]);
+}
+__global__ __launch_bounds__(256) void cam_tta_norm_kernel(dig_cam_tta_norm_args a) {
+    extern __shared__ __attribute__((aligned(16))) float mm[];  // [2][hp*wp] + reduction scratch
+    __shared__ float red[32];
+    const int bc = blockIdx.x, b = bc / a.C, c = bc % a.C;
+    const int P = a.hp * a.wp;
+    float* m0 = mm;
+    float* m1 = mm + P;
+    for (int i = threadIdx.x; i < P; i += 256) {
+        m0[i] = a.rc[(size_t)bc * P + i];
+        m1[i] = a.rc_flip[(size_t)bc * P + i];
+    }
+    __syncthreads();
+    const float lab = a.label[(size_t)b * a.C + c];
+    const float sh = (float)a.hp / (float)a.H, sw = (float)a.wp / (float)a.W;
+    const int HW = a.H * a.W;
+    float mx = -INFINITY, mn = INFINITY;
+    float* out = a.out + (size_t)bc * HW;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const int y = i / a.W, x = i - y * a.W;
+        const float s = bilin(m0, a.hp, a.wp, sh, sw, y, x) * lab + bilin(m1, a.hp, a.wp, sh, sw, y, a.W - 1 - x) * lab;
+        const float rl = fmaxf(s, 0.f);
+        out[i] = rl;
+        mx = fmaxf(mx, rl);
+        mn = fminf(mn, rl);
+    }
+    mx = block_max(mx, red);
+    mn = -block_max(-mn, red);
+    const float den = mx - mn + 1e-5f;
+    for (int i = threadIdx.x; i < HW; i += 256) out[i] = fmaxf(out[i] - mn - 1e-5f, 0.f) / den;  // same thread wrote out[i]
+}
+
+__global__ void cam_argmax_kernel(dig_cam_argmax_args a) {
+    const size_t total = (size_t)a.B * a.HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / a.HW), pix = (int)(i % a.HW);
+        float best = a.threshold;
+        int arg = 0;
+        for (int c = 0; c < a.C; c++) {
+            const float v = a.label[(size_t)b * a.C + c] > 1e-5f ? a.cam[((size_t)b * a.C + c) * a.HW + pix] : 0.f;
+            if (v > best) {  // strict: first maximum wins, like np.argmax
+                best = v;
+                arg = c + 1;
+            }
+        }
+        a.out[i] = (unsigned char)arg;
+    }
+}
+
+inline int grid_for(size_t work, int block, int cap = 256 * 8) {
+    size_t g = (work + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > (size_t)cap ? cap : g));
+}
+
+}  // namespace
+
+#define STREAM hipStream_t stream = (hipStream_t)stream_
+
+extern "C" int dig_patchify(const dig_patchify_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->img && a->rows && a->ps > 0 && a->H % a->ps == 0 && a->W % a->ps == 0, DIG_EINVAL, "patchify: bad argument");
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((size_t)a->B * 3 * a->H * a->W, 256)), dim3(256), 0, stream, *a);
+    DIG_LAUNCH_CHECK("patchify");
+    return DIG_OK;
+}
+
+extern "C" int dig_layernorm(const dig_layernorm_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->x && a->gamma && a->beta && a->out && a->rows > 0 && a->D > 0, DIG_EINVAL, "layernorm: bad argument");
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((a->rows + 3) / 4)), dim3(256), 0, stream, *a);
+    DIG_LAUNCH_CHECK("layernorm");
+    return DIG_OK;
+}
+
+extern "C" int dig_vit_attn(const dig_vit_attn_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->qkv && a->out && a->acc_all, DIG_EINVAL, "vit_attn: null pointer");
+    DIG_CHECK(a->B > 0 && a->N > 0 && a->heads > 0 && (a->dh == 64 || a->dh == 32), DIG_EINVAL, "vit_attn: bad shape (head dim must be 32 or 64)");
+    const int Np = (a->N + 3) & ~3;
+    const size_t lds = (size_t)(2 * TQ * Np + TQ * a->dh) * sizeof(float);
+    DIG_CHECK(lds <= 150 * 1024, DIG_EINVAL, "vit_attn: %d tokens need %zu B of LDS (max 150 KiB)", a->N, lds);
+    const dim3 grid(cdiv(a->N, TQ), a->B);
+    if (a->dh == 64) {
+        (void)hipFuncSetAttribute((const void*)vit_attn_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(vit_attn_kernel<64>, grid, dim3(256), lds, stream, *a);
+    } else {
+        (void)hipFuncSetAttribute((const void*)vit_attn_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(vit_attn_kernel<32>, grid, dim3(256), lds, stream, *a);
+    }
+    DIG_LAUNCH_CHECK("vit_attn");
+    return DIG_OK;
+}
+
+extern "C" int dig_bicubic_pos(const dig_bicubic_pos_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->in && a->out && a->g > 0 && a->ho > 0 && a->wo > 0 && a->rscale_h > 0 && a->rscale_w > 0, DIG_EINVAL, "bicubic_pos: bad argument");
+    hipLaunchKernelGGL(bicubic_pos_kernel, dim3(grid_for((size_t)a->ho * a->wo * a->D, 256)), dim3(256), 0, stream, *a);
+    DIG_LAUNCH_CHECK("bicubic_pos");
+    return DIG_OK;
+}
+
+extern "C" int dig_cam_fuse(const dig_cam_fuse_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->acc_all && a->acc_cls && a->head && a->mtatt && a->cams && a->rcams, DIG_EINVAL, "cam_fuse: null pointer");
+    DIG_CHECK(a->B > 0 && a->C > 0 && a->P > 0 && a->P * 4 <= 64 * 1024, DIG_EINVAL, "cam_fuse: bad shape");
+    hipLaunchKernelGGL(cam_fuse_kernel, dim3(a->B * a->C), dim3(256), (size_t)a->P * 4, stream, *a);
+    DIG_LAUNCH_CHECK("cam_fuse");
+    return DIG_OK;
+}
+
+extern "C" int dig_cam_tta_norm(const dig_cam_tta_norm_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->rc && a->rc_flip && a->label && a->out, DIG_EINVAL, "cam_tta_norm: null pointer");
+    DIG_CHECK(a->B > 0 && a->C > 0 && a->hp > 0 && a->wp > 0 && a->H > 0 && a->W > 0 && (size_t)a->hp * a->wp * 8 <= 60 * 1024, DIG_EINVAL, "cam_tta_norm: bad shape");
+    hipLaunchKernelGGL(cam_tta_norm_kernel, dim3(a->B * a->C), dim3(256), (size_t)a->hp * a->wp * 8, stream, *a);
+    DIG_LAUNCH_CHECK("cam_tta_norm");
+    return DIG_OK;
+}
+
+extern "C" int dig_cam_argmax(const dig_cam_argmax_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->cam && a->label && a->out && a->B > 0 && a->C > 0 && a->C < 255 && a->HW > 0, DIG_EINVAL, "cam_argmax: bad argument");
+    hipLaunchKernelGGL(cam_argmax_kernel, dim3(grid_for((size_t)a->B * a->HW, 256)), dim3(256), 0, stream, *a);
+    DIG_LAUNCH_CHECK("cam_argmax");
+    return DIG_OK;
+}

@@ -47,6 +47,7 @@ typedef struct {
     const float* bias;
     void* out;
     float* stats;
+    long long in0_bstride; /* elements between images of in0; 0 = dense (Hi*Wi*C0) */
     int B, H, W, C0, C1, Cout, groups, up2, dtype;
 } dig_conv3x3_args;
 int dig_conv3x3_tiles(int H, int W);
@@ -238,6 +239,88 @@ typedef struct {
 } dig_layout_args;
 int dig_nchw_f32_to_nhwc(const dig_layout_args* a, void* stream);
 int dig_nhwc_to_nchw_f32(const dig_layout_args* a, void* stream);
+
+/* ======================= MCTformer class-token attention -> CAM path (fp32 throughout) ======================= */
+
+/* PatchEmbed im2row (networks/vision_transformer.py:238-245): img NCHW fp32 [B][3][H][W] -> rows [B*hp*wp][3*ps*ps],
+ * K ordered (c, ky, kx) like the flattened conv weight; followed by dig_gemm_nt with bias (+pos-embed as `res`). */
+typedef struct {
+    const float* img;
+    float* rows;
+    int B, H, W, ps;
+} dig_patchify_args;
+int dig_patchify(const dig_patchify_args* a, void* stream);
+
+/* nn.LayerNorm over the last dim (vision_transformer.py:182,187,192-194), fp32 rows */
+typedef struct {
+    const float* x;
+    const float* gamma;
+    const float* beta;
+    float* out;
+    long long rows;
+    int D;
+    float eps;
+} dig_layernorm_args;
+int dig_layernorm(const dig_layernorm_args* a, void* stream);
+
+/* ViT multi-head attention that also rolls the probabilities up (vision_transformer.py:87-103; mctformer.py:302-303,
+ * 310,314-315): qkv [B][N][3*heads*dh] (q|k|v, head-major inside each third) -> out [B][N][heads*dh];
+ * probs are averaged over heads and ADDED into acc_all [B][N][N] (always) and acc_cls [B][ncls][N] (if non-NULL):
+ * the caller zeroes both once and calls this per layer, passing acc_cls only for the last n_layers layers. */
+typedef struct {
+    const float* qkv;
+    float* out;
+    float* acc_all;
+    float* acc_cls;
+    int B, N, heads, dh, ncls;
+} dig_vit_attn_args;
+int dig_vit_attn(const dig_vit_attn_args* a, void* stream);
+
+/* bicubic (A=-0.75, align_corners=False, coordinates from the GIVEN scale factors as F.interpolate does) resize of the
+ * patch position embedding grid [g][g][D] -> [ho][wo][D]  (mctformer.py:196-217) */
+typedef struct {
+    const float* in;
+    float* out;
+    int g, D, ho, wo;
+    float rscale_h, rscale_w; /* (float)(1.0 / scale_factor), exactly as F.interpolate derives its coordinate scale */
+} dig_bicubic_pos_args;
+int dig_bicubic_pos(const dig_bicubic_pos_args* a, void* stream);
+
+/* CAM aggregation (mctformer.py:305-321): mtatt[b][c][p] = acc_cls[b][c][C+p]; cams = mtatt*relu(head);
+ * rcams[b][c][p] = sum_q acc_all[b][C+p][C+q] * cams[b][c][q].   head: NHWC fp32 [B][P][C] (conv3x3 output). */
+typedef struct {
+    const float* acc_all;
+    const float* acc_cls;
+    const float* head;
+    float* mtatt;
+    float* cams;
+    float* rcams;
+    int B, C, P;
+} dig_cam_fuse_args;
+int dig_cam_fuse(const dig_cam_fuse_args* a, void* stream);
+
+/* infer_multi post-processing (model.py:468-477 + max_norm model.py:572-578):
+ *   s = up(rc)[y][x]*label + up(rc_flip)[y][W-1-x]*label   (bilinear, align_corners=False)
+ *   out = relu(relu(s) - min - 1e-5) / (max - min + 1e-5), min/max of relu(s) over HxW per (b, c).   NCHW fp32. */
+typedef struct {
+    const float* rc;
+    const float* rc_flip;
+    const float* label;
+    float* out;
+    int B, C, hp, wp, H, W;
+} dig_cam_tta_norm_args;
+int dig_cam_tta_norm(const dig_cam_tta_norm_args* a, void* stream);
+
+/* CAM label map (evaluation.py:42-50): labels[b][y][x] = argmax([thr, cam[b][0] if label>1e-5 else 0, ...]) as uint8,
+ * first maximum wins (np.argmax). */
+typedef struct {
+    const float* cam;
+    const float* label;
+    unsigned char* out;
+    int B, C, HW;
+    float threshold;
+} dig_cam_argmax_args;
+int dig_cam_argmax(const dig_cam_argmax_args* a, void* stream);
 
 #ifdef __cplusplus
 }
