@@ -1,0 +1,46 @@
+"""Data-parallel sharding of the guidance/CAM path: one process per GPU (torch.distributed; backend "nccl" is RCCL
+over xGMI on ROCm, "gloo" in CPU tests).  Images are independent (GroupNorm is per sample, attention is per image,
+ViT tokens never mix across the batch), so the only communication is ONE all-gather of the per-rank results."""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_items, world, rank):
+    """Contiguous, balanced split of n_items over world ranks -> (lo, hi) of `rank`."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_gather_batch(local, n_items=None, group=None):
+    """Gather per-rank batches [b_r, ...] into [sum b_r, ...] on every rank with a single collective.
+    Equal shards use all_gather_into_tensor directly; ragged shards are padded to the largest shard first."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    local = local.contiguous()
+    if n_items is None or n_items % world == 0:
+        out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local, group=group)
+        return out
+    sizes = [shard_bounds(n_items, world, r) for r in range(world)]
+    mx = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return torch.cat([out[r * mx:r * mx + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], 0)
+
+
+def run_sharded(fn, *batched_inputs, group=None):
+    """Split every input along dim 0 over the ranks, run fn on the local shard, all-gather each output.
+    fn returns a tensor or a tuple/list of tensors whose dim 0 is the (local) batch."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = batched_inputs[0].shape[0]
+    lo, hi = shard_bounds(n, world, rank)
+    outs = fn(*[x[lo:hi] for x in batched_inputs])
+    single = torch.is_tensor(outs)
+    outs = [outs] if single else list(outs)
+    res = [all_gather_batch(o, n, group) for o in outs]
+    return res[0] if single else res

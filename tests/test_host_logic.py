@@ -1,0 +1,111 @@
+"""CPU tier: host-side logic - the C-ABI library loads and exports every symbol include/dig_hip.h declares (no compute
+calls without a GPU), argument structs mirror the header, product modules keep the reference's state_dict keys and
+refuse to run off-device (no CPU fallback), synthetic generators are deterministic, sharding + all-gather (gloo, 2 ranks)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from dig_amd import _lib, synth
+from dig_amd.diffusion import GaussianDiffusion, Unet
+from dig_amd.mctformer import create_model
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    with open(os.path.join(ROOT, "include", "dig_hip.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    declared = re.findall(r"\b(dig_[a-z0-9_]+)\s*\(", text)
+    assert len(declared) >= 27 and set(declared) == set(_lib.FUNCTIONS)
+    L = _lib.lib()
+    for fn in declared:
+        assert hasattr(L, fn), fn
+    assert L.dig_version() >= 100
+    assert L.dig_conv3x3_tiles(256, 256) == 256 and L.dig_conv3x3_tiles(28, 28) == 4
+
+
+def test_struct_mirror_sizes():
+    # every pointer is 8 bytes, long long 8, int/float 4: ctypes must agree with the C compiler's layout
+    S = _lib.STRUCTS["dig_gemm_args"]
+    assert ctypes.sizeof(S) == 8 * 8 + 10 * 8 + 22 * 4 + 4 + 4  # 8 ptrs, 10 strides, 22 ints, alpha, tail pad
+    assert ctypes.sizeof(_lib.STRUCTS["dig_conv3x3_args"]) == 7 * 8 + 8 + 9 * 4 + 4
+    assert [f for f, _ in _lib.STRUCTS["dig_stem_args"]._fields_][-7:] == ["pre_scale", "pre_shift", "B", "H", "W", "Cout", "dtype"]
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu():
+    L = _lib.lib()
+    a = _lib.STRUCTS["dig_gemm_args"]()
+    assert L.dig_gemm_nt(ctypes.byref(a), None) == -1 and b"null pointer" in L.dig_last_error()
+    c = _lib.STRUCTS["dig_conv3x3_args"]()
+    assert L.dig_conv3x3(ctypes.byref(c), None) == -1
+
+
+def test_state_dict_keys_and_no_cpu_fallback():
+    u = Unet(dim=64, dim_mults=(1, 2, 4, 8), flash_attn=True)
+    gd = GaussianDiffusion(u, image_size=224, timesteps=1000, sampling_timesteps=150).eval()
+    sd = gd.state_dict()
+    assert len(sd) == 287 and sum(p.numel() for p in u.parameters()) == 35710339
+    for k in ("model.downs.0.2.norm.g", "model.downs.0.2.to_qkv.weight", "model.downs.0.2.to_out.0.weight", "model.downs.0.2.to_out.1.g",
+              "model.downs.0.3.1.weight", "model.downs.3.3.weight", "model.mid_attn.to_out.bias", "model.ups.0.0.mlp.1.weight",
+              "model.ups.2.3.1.bias", "model.final_res_block.res_conv.weight", "model.time_mlp.3.bias", "sqrt_alphas_cumprod", "loss_weight"):
+        assert k in sd, k
+    assert abs(float(gd.sqrt_alphas_cumprod[100]) - 0.97979611) < 1e-7
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        gd.p_losses(torch.zeros(1, 3, 32, 32), torch.zeros(1, dtype=torch.long), noise=torch.zeros(1, 3, 32, 32))
+    m = create_model("deit_small_MCTformerV2_DiG", pretrained=False, num_classes=20, drop_rate=0.0, drop_path_rate=0.1, drop_block_rate=None)
+    keys = set(m.state_dict())
+    assert {"cls_token", "pos_embed", "patch_embed.proj.weight", "blocks.11.mlp.fc2.bias", "blocks.0.attn.qkv.bias", "norm.weight", "head.weight"} <= keys
+    assert m.state_dict()["pos_embed"].shape == (1, 216, 384)
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        m(torch.zeros(1, 3, 224, 224), return_att=True)
+    with pytest.raises(NotImplementedError):
+        Unet(dim=64, self_condition=True)
+
+
+def test_synth_is_deterministic_and_keyed():
+    a, b = synth.synth_param("downs.0.0.block1.proj.weight", (64, 64, 3, 3)), synth.synth_param("downs.0.0.block1.proj.weight", (64, 64, 3, 3))
+    assert torch.equal(a, b) and abs(float(a.var()) - 1 / 576) < 2e-4
+    assert not torch.equal(a, synth.synth_param("downs.0.1.block1.proj.weight", (64, 64, 3, 3)))
+    assert abs(float(synth.synth_param("x.norm.weight", (64,)).mean()) - 1.0) < 0.05
+    n = synth.synth_noise(2, 64, 64)
+    assert abs(float(n.mean())) < 0.02 and abs(float(n.std()) - 1.0) < 0.02
+    assert float(a.flatten()[0]) == pytest.approx(float(synth.uniform_pm1("downs.0.0.block1.proj.weight", (1,))) * (3 / 576) ** 0.5)
+
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from dig_amd import dist as dd
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n = int(sys.argv[2])
+x = torch.arange(n * 6, dtype=torch.float32).reshape(n, 2, 3)
+def fn(xs):  # stand-in for the per-image guidance forward: any per-sample function
+    return xs * 2 + 1, xs.sum((1, 2))
+a, b = dd.run_sharded(fn, x)
+ra, rb = fn(x)
+assert torch.equal(a, ra) and torch.equal(b, rb), (rank, a.shape)
+lo, hi = dd.shard_bounds(n, world, rank)
+assert hi - lo in (n // world, n // world + 1)
+dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+@pytest.mark.parametrize("n", [8, 7])
+def test_sharded_all_gather_gloo_world2(tmp_path, n):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    procs = []
+    port = 29500 + (os.getpid() % 500) + n
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(n)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=120)
+        assert p.returncode == 0, out.decode()
