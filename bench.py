@@ -76,16 +76,16 @@ def main():
     orig_conv = ops.conv3x3
     state = {"on": False}
 
-    def conv_timed(x0_, w, bias, x1=None, aff=None, up2=False, want_stats=True, groups=8):
+    def conv_timed(x0_, cw, x1=None, aff=None, up2=False, want_stats=True, groups=8):
         if not state["on"]:
-            return orig_conv(x0_, w, bias, x1=x1, aff=aff, up2=up2, want_stats=want_stats, groups=groups)
+            return orig_conv(x0_, cw, x1=x1, aff=aff, up2=up2, want_stats=want_stats, groups=groups)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        out = orig_conv(x0_, w, bias, x1=x1, aff=aff, up2=up2, want_stats=want_stats, groups=groups)
+        out = orig_conv(x0_, cw, x1=x1, aff=aff, up2=up2, want_stats=want_stats, groups=groups)
         e1.record()
         Bc, Hc, Wc, Co = out[0].shape
         cls = "conv3x3_bn128" if Co % 128 == 0 else ("conv3x3_bn64" if Co > 32 else "conv3x3_bn32")
-        conv_log.append((cls, 2.0 * Bc * Hc * Wc * Co * w.shape[-1] * 9, e0, e1))
+        conv_log.append((cls, 2.0 * Bc * Hc * Wc * Co * (cw.C0 + cw.C1) * 9, e0, e1))
         return out
 
     ops.conv3x3 = conv_timed

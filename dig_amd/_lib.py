@@ -9,7 +9,7 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "dig_hip.h")
-LIB_PATH = os.path.join(_HERE, "csrc", "libdig_hip.so")
+LIB_PATH = os.environ.get("DIG_HIP_LIB", os.path.join(_HERE, "csrc", "libdig_hip.so"))  # override only for A/B kernel experiments
 
 DIG_BF16, DIG_F32 = 0, 1
 

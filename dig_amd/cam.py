@@ -31,8 +31,7 @@ def _pack(m):
             n1=(f(blk.norm1.weight), f(blk.norm1.bias)), n2=(f(blk.norm2.weight), f(blk.norm2.bias)),
             qkv=(f(blk.attn.qkv.weight), f(blk.attn.qkv.bias)), proj=(f(blk.attn.proj.weight), f(blk.attn.proj.bias)),
             fc1=(f(blk.mlp.fc1.weight), f(blk.mlp.fc1.bias)), fc2=(f(blk.mlp.fc2.weight), f(blk.mlp.fc2.bias))))
-    P["head_w"] = f(m.head.weight.permute(0, 2, 3, 1))  # [C,3,3,384]
-    P["head_b"] = f(m.head.bias)
+    P["head"] = ops.ConvWeight(m.head.weight, m.head.bias, F32)
     P["pos_cache"] = {}
     m._packed = P
     return P
@@ -100,7 +99,7 @@ def mctformer_forward(m, img, n_layers=12):
         x = ops.linear_rows(hdn, bp["fc2"][0], bias=bp["fc2"][1], res=x)
     # head conv3x3 on the patch tokens viewed as NHWC [B,hp,wp,D] (batch stride N*D, offset C*D)
     head = torch.empty(B, hp, wp, C, dtype=F32, device=dev)
-    call("conv3x3", in0=x.data_ptr() + C * D * 4, in1=None, aff0=None, w=P["head_w"], bias=P["head_b"], out=head, stats=None,
+    call("conv3x3", in0=x.data_ptr() + C * D * 4, in1=None, aff0=None, w=P["head"].w, bias=P["head"].bias, out=head, stats=None,
          in0_bstride=N * D, B=B, H=hp, W=wp, C0=D, C1=0, Cout=C, groups=1, up2=0, dtype=1)
     mtatt = torch.empty(B, C, hp, wp, dtype=F32, device=dev)
     cams = torch.empty_like(mtatt)

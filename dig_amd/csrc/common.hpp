@@ -100,7 +100,8 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (1 ulp): no IEEE division sequence in the conv loader's prologue
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

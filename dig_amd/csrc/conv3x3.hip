@@ -17,6 +17,15 @@ namespace {
 constexpr int TILE = 16;           // 16x16 output pixels per block
 constexpr int HALO = TILE + 2;     // 18
 constexpr int NTHREADS = 256;
+#ifndef CONV_WAVES
+#define CONV_WAVES 2
+#endif
+#ifndef CONV_PF64
+#define CONV_PF64 true
+#endif
+#ifndef CONV_PF128
+#define CONV_PF128 false
+#endif
 
 template <typename T, int KC> struct ConvCfg {
     static constexpr int KCP = KC + 8;  // padded per-pixel channel stride (elements)
@@ -27,15 +36,17 @@ template <typename T, int KC> struct ConvCfg {
 template <typename T, int BN, int KC> constexpr size_t conv_lds_bytes() {
     using C = ConvCfg<T, KC>;
     size_t main = (size_t)(C::HALO_ELEMS + 9 * BN * C::KCP) * sizeof(T);
-    size_t epi = (size_t)(4 * 2 * BN * 2 + BN * 2) * sizeof(float);
-    return main > epi ? main : epi;
+    size_t epi = (size_t)128 * (BN + 4) * sizeof(float);               // output staging, one 128-pixel half at a time
+    size_t st = (size_t)(4 * 2 * BN * 2 + BN * 2) * sizeof(float);     // GroupNorm partials
+    size_t m = main > epi ? main : epi;
+    return m > st ? m : st;
 }
 
 template <typename T> struct Params {
     const T* in[2];
     int C[2];
     const float* aff0;
-    const T* w;
+    const T* w;  // packed [n_tile][chunk][9][BN][KC]
     const float* bias;
     T* out;
     float* stats;
@@ -43,12 +54,14 @@ template <typename T> struct Params {
     int B, H, W, Cout, groups, up2, tiles_x, tiles_y;
 };
 
-template <typename T, int BN, int KC>
-__global__ __launch_bounds__(NTHREADS) void conv3x3_kernel(Params<T> p) {
+template <typename T, int BN, int KC, bool PF>
+__global__ __launch_bounds__(NTHREADS, CONV_WAVES) void conv3x3_kernel(Params<T> p) {
     using C = ConvCfg<T, KC>;
     constexpr int KCP = C::KCP, HROW = C::HROW;
     constexpr int NR = BN / 32, MR = 2;
     constexpr int V = KC / 8;  // 8-element vectors per pixel per chunk
+    constexpr int NH = (HALO * HALO * V + NTHREADS - 1) / NTHREADS;  // halo vectors per thread per chunk
+    constexpr int NW = (9 * BN * V + NTHREADS - 1) / NTHREADS;       // weight vectors per thread per chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* halo = reinterpret_cast<T*>(smem_raw);
     T* wl = halo + C::HALO_ELEMS;
@@ -59,8 +72,9 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_kernel(Params<T> p) {
     const int b = blockIdx.x / tiles, tile = blockIdx.x % tiles;
     const int ty0 = (tile / p.tiles_x) * TILE, tx0 = (tile % p.tiles_x) * TILE;
     const int n0 = blockIdx.y * BN;
-    const int Cin = p.C[0] + p.C[1];
     const int Hs = p.up2 ? p.H >> 1 : p.H, Ws = p.up2 ? p.W >> 1 : p.W;  // source dims
+    const int nch0 = (p.C[0] + KC - 1) / KC, nch1 = (p.C[1] + KC - 1) / KC, nch = nch0 + nch1;
+    const T* wbase = p.w + (size_t)blockIdx.y * nch * (9 * BN * KC);
 
     f32x16 acc[MR][NR];
 #pragma unroll
@@ -71,60 +85,87 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_kernel(Params<T> p) {
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
     const int c8 = tid % V;  // this thread's vector slot inside a chunk (constant: 256 % V == 0)
-    // One flat loop over the K-chunks of both concat pieces (a nested piece/chunk loop made hipcc shuttle an
-    // accumulator register through a VGPR copy at the inner loop's exit, read before the last MFMA had retired).
-    const int nch0 = (p.C[0] + KC - 1) / KC, nch1 = (p.C[1] + KC - 1) / KC;
-    for (int ci = 0; ci < nch0 + nch1; ci++) {
+    Frag<T> hreg[NH], wreg[NW];
+    unsigned hok = 0;  // bit i: hreg[i] holds real (in-bounds) data
+
+    // global -> registers for chunk ci (weights: one contiguous pre-packed slab, perfectly coalesced)
+    auto gload = [&](int ci) {
         const int piece = ci >= nch0 ? 1 : 0;
         const int cb = (ci - (piece ? nch0 : 0)) * KC;
         const int Cp = p.C[piece];
         const T* src = p.in[piece];
-        const int koff = piece ? p.C[0] : 0;
-        const bool pro = (piece == 0) && (p.aff0 != nullptr);
+        const size_t bs = piece ? (size_t)Hs * Ws * Cp : (size_t)p.bstride0;
         const int ch = cb + c8 * 8;
         const bool chv = ch < Cp;
-        float pa[8], pb[8];
-        if (pro && chv) {
-            const float* af = p.aff0 + ((size_t)b * Cp + ch) * 2;
+        hok = 0;
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                pa[j] = af[2 * j];
-                pb[j] = af[2 * j + 1];
-            }
-        }
-        __syncthreads();  // previous chunk's MFMA reads are done
-        // ---- halo tile: 18*18 pixels x V vectors
-        for (int idx = tid; idx < HALO * HALO * V; idx += NTHREADS) {
+        for (int i = 0; i < NH; i++) {
+            const int idx = tid + i * NTHREADS;
             const int pix = idx / V;
             const int hy = pix / HALO, hx = pix - hy * HALO;
             const int Y = ty0 + hy - 1, X = tx0 + hx - 1;
-            Frag<T> f;
-            const bool ok = chv && Y >= 0 && Y < p.H && X >= 0 && X < p.W;
+            const bool ok = (idx < HALO * HALO * V) && chv && Y >= 0 && Y < p.H && X >= 0 && X < p.W;
             if (ok) {
                 const int sy = p.up2 ? Y >> 1 : Y, sx = p.up2 ? X >> 1 : X;
-                frag_load<T>(f, src + (size_t)b * (piece ? (size_t)Hs * Ws * Cp : (size_t)p.bstride0) + ((size_t)sy * Ws + sx) * Cp + ch);
-                if (pro) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) frag_set<T>(f, j, silu_f(pa[j] * frag_get<T>(f, j) + pb[j]));
-                }
+                frag_load<T>(hreg[i], src + (size_t)b * bs + ((size_t)sy * Ws + sx) * Cp + ch);
+                hok |= 1u << i;
             } else {
-                frag_zero<T>(f);
+                frag_zero<T>(hreg[i]);
             }
-            frag_store<T>(f, halo + hy * HROW + hx * KCP + c8 * 8);
         }
-        // ---- weight slab [9][BN][KC] <- w[n][tap][koff+cb+..]
-        for (int idx = tid; idx < 9 * BN * V; idx += NTHREADS) {
-            const int row = idx / V;  // tap*BN + n
-            const int tap = row / BN, n = row - tap * BN;
-            Frag<T> f;
-            if (chv && (n0 + n) < p.Cout)
-                frag_load<T>(f, p.w + ((size_t)(n0 + n) * 9 + tap) * Cin + koff + ch);
-            else
-                frag_zero<T>(f);
-            frag_store<T>(f, wl + row * KCP + c8 * 8);
+        const T* slab = wbase + (size_t)ci * (9 * BN * KC);
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            const int idx = tid + i * NTHREADS;
+            if (idx < 9 * BN * V) frag_load<T>(wreg[i], slab + (size_t)idx * 8);
         }
+    };
+    // registers -> LDS (GroupNorm-apply + SiLU prologue applied here, once per input element)
+    auto lstore = [&](int ci) {
+        const bool pro = (ci < nch0) && (p.aff0 != nullptr);
+        if (pro) {
+            const int ch = ci * KC + c8 * 8;
+            if (ch < p.C[0]) {
+                const float* af = p.aff0 + ((size_t)b * p.C[0] + ch) * 2;
+                float pa[8], pb[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    pa[j] = af[2 * j];
+                    pb[j] = af[2 * j + 1];
+                }
+#pragma unroll
+                for (int i = 0; i < NH; i++)
+                    if (hok & (1u << i)) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) frag_set<T>(hreg[i], j, silu_f(pa[j] * frag_get<T>(hreg[i], j) + pb[j]));
+                    }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NH; i++) {
+            const int idx = tid + i * NTHREADS;
+            if (idx < HALO * HALO * V) {
+                const int pix = idx / V;
+                const int hy = pix / HALO, hx = pix - hy * HALO;
+                frag_store<T>(hreg[i], halo + hy * HROW + hx * KCP + c8 * 8);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            const int idx = tid + i * NTHREADS;
+            if (idx < 9 * BN * V) frag_store<T>(wreg[i], wl + (idx / V) * KCP + c8 * 8);
+        }
+    };
+
+    // One flat loop over the K-chunks of both concat pieces (a nested piece/chunk loop made hipcc shuttle an
+    // accumulator register through a VGPR copy at the inner loop's exit, read before the last MFMA had retired).
+    if (PF) gload(0);
+    for (int ci = 0; ci < nch; ci++) {
+        if (!PF) gload(ci);
+        __syncthreads();  // previous chunk's MFMA reads are done
+        lstore(ci);
         __syncthreads();
-        // ---- 9 taps x KC/16 MFMA steps
+        if (PF && ci + 1 < nch) gload(ci + 1);  // next chunk's HBM/L2 latency hides under this chunk's MFMAs
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             const int ky = tap / 3, kx = tap - ky * 3;
@@ -146,38 +187,61 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_kernel(Params<T> p) {
             }
         }
     }
-    // Let the last MFMA retire before anything reads the accumulators (16-pass MFMA -> VALU read needs 18 wait
-    // states; do not rely on the hazard recognizer across the loop exit), and fence LDS for the epilogue.
+    // Let the last MFMA retire before anything reads the accumulators (do not rely on the hazard recognizer across
+    // the loop exit), and fence LDS for the epilogue.
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
 
-    // ---- epilogue: bias, store, GroupNorm partials
+    // ---- epilogue: +bias, GroupNorm partials from the fp32 accumulators, and the output tile transposed through
+    // LDS (fp32, one 128-pixel half at a time) so that HBM sees 16-byte stores of 8 consecutive channels.
+    float* ot = reinterpret_cast<float*>(smem_raw);
+    constexpr int OS = BN + 4;
     float cs[NR], css[NR];
 #pragma unroll
-    for (int nr = 0; nr < NR; nr++) {
-        const int n = n0 + nr * 32 + r;
-        const bool nv = n < p.Cout;
-        const float bias = nv ? p.bias[n] : 0.f;
-        float s = 0.f, ss = 0.f;
+    for (int nr = 0; nr < NR; nr++) cs[nr] = css[nr] = 0.f;
+    const bool vec_ok = (p.Cout % 8) == 0;
 #pragma unroll
-        for (int mr = 0; mr < MR; mr++) {
+    for (int mr = 0; mr < MR; mr++) {
+#pragma unroll
+        for (int nr = 0; nr < NR; nr++) {
+            const int n = n0 + nr * 32 + r;
+            const bool nv = n < p.Cout;
+            const float bias = nv ? p.bias[n] : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                const int row = acc_row(e, lane);  // 0..31 inside the M sub-tile
-                const int py = wave * 4 + mr * 2 + (row >> 4), px = row & 15;
-                const int Y = ty0 + py, X = tx0 + px;
+                const int row = acc_row(e, lane);
+                const int Y = ty0 + wave * 4 + mr * 2 + (row >> 4), X = tx0 + (row & 15);
+                const float v = acc[mr][nr][e] + bias;
+                ot[(wave * 32 + row) * OS + nr * 32 + r] = v;
                 if (nv && Y < p.H && X < p.W) {
-                    const float v = acc[mr][nr][e] + bias;
-                    p.out[(((size_t)b * p.H + Y) * p.W + X) * p.Cout + n] = from_f32<T>(v);
-                    s += v;
-                    ss += v * v;
+                    cs[nr] += v;
+                    css[nr] += v * v;
                 }
             }
         }
-        cs[nr] = s;
-        css[nr] = ss;
+        __syncthreads();
+        for (int idx = tid; idx < 128 * (BN / 8); idx += NTHREADS) {
+            const int pl = idx / (BN / 8), v8 = idx - pl * (BN / 8);
+            const int wv = pl >> 5, row = pl & 31;
+            const int Y = ty0 + wv * 4 + mr * 2 + (row >> 4), X = tx0 + (row & 15);
+            const int n = n0 + v8 * 8;
+            if (Y < p.H && X < p.W && n < p.Cout) {
+                const float* sp = ot + pl * OS + v8 * 8;
+                T* dst = p.out + (((size_t)b * p.H + Y) * p.W + X) * p.Cout + n;
+                if (vec_ok) {
+                    Frag<T> f;
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(sp), hi = *reinterpret_cast<const f32x4*>(sp + 4);
+                    frag_set<T>(f, 0, lo[0]); frag_set<T>(f, 1, lo[1]); frag_set<T>(f, 2, lo[2]); frag_set<T>(f, 3, lo[3]);
+                    frag_set<T>(f, 4, hi[0]); frag_set<T>(f, 5, hi[1]); frag_set<T>(f, 6, hi[2]); frag_set<T>(f, 7, hi[3]);
+                    frag_store<T>(f, dst);
+                } else {
+                    for (int j = 0; j < 8 && n + j < p.Cout; j++) dst[j] = from_f32<T>(sp[j]);
+                }
+            }
+        }
+        __syncthreads();
     }
     if (p.stats != nullptr) {
         float* st = reinterpret_cast<float*>(smem_raw);  // [wave][half][BN][2], then [BN][2]
@@ -218,7 +282,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_kernel(Params<T> p) {
     }
 }
 
-template <typename T, int BN, int KC>
+template <typename T, int BN, int KC, bool PF>
 int launch(const dig_conv3x3_args* a, hipStream_t stream) {
     Params<T> p;
     p.in[0] = (const T*)a->in0;
@@ -240,20 +304,34 @@ int launch(const dig_conv3x3_args* a, hipStream_t stream) {
     (void)hipGetDevice(&dev);
     dev &= 63;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel<T, BN, KC>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel<T, BN, KC, PF>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "conv3x3: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
         attr_set[dev] = true;
     }
     dim3 grid(a->B * p.tiles_x * p.tiles_y, cdiv(a->Cout, BN));
-    hipLaunchKernelGGL((conv3x3_kernel<T, BN, KC>), grid, dim3(NTHREADS), lds, stream, p);
+    hipLaunchKernelGGL((conv3x3_kernel<T, BN, KC, PF>), grid, dim3(NTHREADS), lds, stream, p);
     DIG_LAUNCH_CHECK("conv3x3");
     return DIG_OK;
+}
+
+// tile configuration per (Cout, dtype): the weight packer (host) and the launcher must agree
+void conv_config(int Cout, int dtype, int* BN, int* KC) {
+    int bn = (Cout % 128 == 0) ? 128 : (Cout > 32 ? 64 : 32);
+    if (dtype == DIG_F32 && bn > 64) bn = 64;
+    *BN = bn;
+    *KC = (dtype == DIG_F32) ? 16 : (bn == 32 ? 32 : 16);
 }
 
 }  // namespace
 
 extern "C" int dig_conv3x3_tiles(int H, int W) { return cdiv(H, TILE) * cdiv(W, TILE); }
+
+extern "C" int dig_conv3x3_config(int Cout, int dtype, int* BN, int* KC) {
+    DIG_CHECK(Cout > 0 && BN && KC && (dtype == DIG_BF16 || dtype == DIG_F32), DIG_EINVAL, "conv3x3_config: bad argument");
+    conv_config(Cout, dtype, BN, KC);
+    return DIG_OK;
+}
 
 extern "C" int dig_conv3x3(const dig_conv3x3_args* a, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -264,8 +342,9 @@ extern "C" int dig_conv3x3(const dig_conv3x3_args* a, void* stream_) {
     DIG_CHECK(!a->up2 || (a->H % 2 == 0 && a->W % 2 == 0), DIG_EINVAL, "conv3x3: up2 needs even H,W");
     DIG_CHECK(((uintptr_t)a->in0 | (uintptr_t)a->in1 | (uintptr_t)a->w | (uintptr_t)a->out) % 16 == 0, DIG_EALIGN,
               "conv3x3: pointers must be 16-byte aligned");
-    int BN = (a->Cout % 128 == 0) ? 128 : (a->Cout > 32 ? 64 : 32);
-    if (a->dtype == DIG_F32 && BN > 64) BN = 64;
+    DIG_CHECK(a->dtype == DIG_BF16 || a->dtype == DIG_F32, DIG_EINVAL, "conv3x3: unknown dtype %d", a->dtype);
+    int BN, KC;
+    conv_config(a->Cout, a->dtype, &BN, &KC);
     if (a->stats) {
         DIG_CHECK(a->groups > 0 && a->Cout % a->groups == 0, DIG_EINVAL, "conv3x3: Cout %% groups != 0");
         const int cpg = a->Cout / a->groups;
@@ -273,12 +352,10 @@ extern "C" int dig_conv3x3(const dig_conv3x3_args* a, void* stream_) {
                   "conv3x3: GroupNorm group width %d does not tile the %d-channel block", cpg, BN);
     }
     if (a->dtype == DIG_BF16) {
-        if (BN == 128) return launch<bf16, 128, 16>(a, stream);
-        if (BN == 64) return launch<bf16, 64, 32>(a, stream);
-        return launch<bf16, 32, 32>(a, stream);
-    } else if (a->dtype == DIG_F32) {
-        if (BN >= 64) return launch<float, 64, 16>(a, stream);
-        return launch<float, 32, 16>(a, stream);
+        if (BN == 128) return launch<bf16, 128, 16, CONV_PF128>(a, stream);
+        if (BN == 64) return launch<bf16, 64, 16, CONV_PF64>(a, stream);
+        return launch<bf16, 32, 32, true>(a, stream);
     }
-    DIG_CHECK(false, DIG_EINVAL, "conv3x3: unknown dtype %d", a->dtype);
+    if (BN == 64) return launch<float, 64, 16, false>(a, stream);
+    return launch<float, 32, 16, false>(a, stream);
 }

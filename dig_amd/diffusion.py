@@ -200,8 +200,9 @@ class Unet(nn.Module):
         return pred if self.training else (pred, feats)
 
 
-def _conv3_pack(conv, dt):
-    return conv.weight.detach().permute(0, 2, 3, 1).contiguous().to(dt), conv.bias.detach().float().contiguous()
+def _conv3_pack(conv, dt, C1=0):
+    """-> ops.ConvWeight; C1 = channels of the second half when the conv reads a fused (x | skip) concat."""
+    return ops.ConvWeight(conv.weight, conv.bias, dt, C1=C1)
 
 
 def _conv1_pack(conv, dt):
@@ -218,11 +219,11 @@ def _pack_unet(u, dt):
     P["t3"] = (f32(u.time_mlp[3].weight), f32(u.time_mlp[3].bias))
     mlps_w, mlps_b, off = [], [], [0]
 
-    def rb(m):
+    def rb(m, C1=0):
         d = {}
-        d["w1"], d["b1"] = _conv3_pack(m.block1.proj, dt)
+        d["w1"] = _conv3_pack(m.block1.proj, dt, C1)
         d["g1"], d["be1"] = f32(m.block1.norm.weight), f32(m.block1.norm.bias)
-        d["w2"], d["b2"] = _conv3_pack(m.block2.proj, dt)
+        d["w2"] = _conv3_pack(m.block2.proj, dt)
         d["g2"], d["be2"] = f32(m.block2.norm.weight), f32(m.block2.norm.bias)
         d["eps"] = m.block1.norm.eps
         d["res"] = _conv1_pack(m.res_conv, dt) if isinstance(m.res_conv, nn.Conv2d) else None
@@ -246,27 +247,33 @@ def _pack_unet(u, dt):
             d["g2"] = f32(m.to_out[1].g.reshape(-1))
         return d
 
-    def stage(blocks, is_down):
+    def stage(blocks, is_down, skip_c=(0, 0)):
         b1, b2, at, smp = blocks
-        d = {"rb1": rb(b1), "rb2": rb(b2), "attn": attn(at)}
+        d = {"rb1": rb(b1, skip_c[0]), "rb2": rb(b2, skip_c[1]), "attn": attn(at)}
         if isinstance(smp, nn.Conv2d):
             d["kind"] = "conv"
-            d["w"], d["b"] = _conv3_pack(smp, dt)
+            d["w"] = _conv3_pack(smp, dt)
+            d["cout"] = smp.weight.shape[0]
         elif is_down:
             d["kind"] = "down"
             w = smp[1].weight.detach()
             co, c4 = w.shape[0], w.shape[1]
             d["w"] = w.reshape(co, c4 // 4, 2, 2).permute(0, 2, 3, 1).reshape(co, c4).contiguous().to(dt)
             d["b"] = f32(smp[1].bias)
+            d["cout"] = co
         else:
             d["kind"] = "up"
-            d["w"], d["b"] = _conv3_pack(smp[1], dt)
+            d["w"] = _conv3_pack(smp[1], dt)
+            d["cout"] = smp[1].weight.shape[0]
         return d
 
     P["downs"] = [stage(s, True) for s in u.downs]
     P["mid1"], P["mid_attn"], P["mid2"] = rb(u.mid_block1), attn(u.mid_attn), rb(u.mid_block2)
-    P["ups"] = [stage(s, False) for s in u.ups]
-    P["final_rb"] = rb(u.final_res_block)
+    # skip connections popped by the ups path: stage j reads (x | h.pop()) twice; both skips of a level have dim_in channels
+    n = len(u.downs)
+    dims = [u.dim] + [u.downs[i][3][1].weight.shape[0] if i < n - 1 else u.downs[i][3].weight.shape[0] for i in range(n)]
+    P["ups"] = [stage(s, False, (dims[n - 1 - j], dims[n - 1 - j])) for j, s in enumerate(u.ups)]
+    P["final_rb"] = rb(u.final_res_block, u.dim)
     P["final_w"], P["final_b"] = _conv1_pack(u.final_conv, dt)
     P["mlp_w"], P["mlp_b"] = torch.cat(mlps_w, 0).contiguous(), torch.cat(mlps_b, 0).contiguous()
     dev = u.init_conv.weight.device
@@ -281,9 +288,9 @@ def _pack_unet(u, dt):
 def _resnet(p, x0, x1, ss_all, debug=None):
     """ResnetBlock (ddp.py:169-194); x1 = second half of a fused channel concat (or None)."""
     hw = x0.shape[1] * x0.shape[2]
-    c1, st1 = ops.conv3x3(x0, p["w1"], p["b1"], x1=x1)
+    c1, st1 = ops.conv3x3(x0, p["w1"], x1=x1)
     aff1 = ops.gn_finalize(st1, p["g1"], p["be1"], hw, ss=ss_all, ss_off=p["ss_off"], eps=p["eps"])
-    c2, st2 = ops.conv3x3(c1, p["w2"], p["b2"], aff=aff1)
+    c2, st2 = ops.conv3x3(c1, p["w2"], aff=aff1)
     aff2 = ops.gn_finalize(st2, p["g2"], p["be2"], hw, eps=p["eps"])
     if p["res"] is None:
         assert x1 is None
@@ -393,14 +400,14 @@ def _unet_forward(u, img, noise, t, sqrt_ac, sqrt_1mac, pre_scale, pre_shift, wa
         if s["kind"] == "down":
             x = ops.downsample_conv(x, s["w"], s["b"])
         else:
-            x, _ = ops.conv3x3(x, s["w"], s["b"], want_stats=False)
+            x, _ = ops.conv3x3(x, s["w"], want_stats=False)
         keep(f"downs.{i}.out", x)
     x = _resnet(P["mid1"], x, None, ss)
     x = _full_attention(P["mid_attn"], x)
     x = _resnet(P["mid2"], x, None, ss)
     keep("mid", x)
     h, w = H // 16, W // 16
-    chans = [x.shape[-1]] + [s["w"].shape[0] for s in P["ups"]]
+    chans = [x.shape[-1]] + [s["cout"] for s in P["ups"]]
     maps = torch.empty(B, sum(chans), h, w, dtype=torch.float32, device=dev)
     ops.bilinear_ac_into(x, maps, 0)
     coff = chans[0]
@@ -409,7 +416,7 @@ def _unet_forward(u, img, noise, t, sqrt_ac, sqrt_1mac, pre_scale, pre_shift, wa
         x = _resnet(s["rb2"], x, skips.pop(), ss)
         x = _full_attention(s["attn"], x) if s["attn"]["full"] else _linear_attention(s["attn"], x)
         keep(f"ups.{j}.attn", x)
-        x, _ = ops.conv3x3(x, s["w"], s["b"], up2=(s["kind"] == "up"), want_stats=False)
+        x, _ = ops.conv3x3(x, s["w"], up2=(s["kind"] == "up"), want_stats=False)
         keep(f"ups.{j}.out", x)
         ops.bilinear_ac_into(x, maps, coff)
         coff += chans[j + 1]

@@ -13,20 +13,49 @@ def _chk(t):
     return t
 
 
-def conv3x3(x0, w, bias, x1=None, aff=None, up2=False, want_stats=True, groups=GN_GROUPS):
-    """x0,x1: [B,h,w,C]; w packed [Cout,3,3,C0+C1]; returns (out [B,H,W,Cout], stats or None)."""
+class ConvWeight:
+    """A conv3x3 weight packed as the kernel's per-chunk LDS slabs: [n_tile][chunk][9][BN][KC] (zero padded),
+    chunks = ceil(C0/KC) + ceil(C1/KC) for a (C0 | C1) channel concat.  (BN, KC) come from dig_conv3x3_config."""
+
+    def __init__(self, w_oihw, bias, dtype, C1=0):
+        import ctypes
+        Co, Cin = w_oihw.shape[0], w_oihw.shape[1]
+        C0 = Cin - C1
+        bn, kc = ctypes.c_int(), ctypes.c_int()
+        rc = _lib.lib().dig_conv3x3_config(Co, dtype_code(dtype), ctypes.byref(bn), ctypes.byref(kc))
+        assert rc == 0
+        BN, KC = bn.value, kc.value
+        w = w_oihw.detach().float().permute(0, 2, 3, 1).reshape(Co, 9, Cin)  # [Co][tap][Cin]
+        pieces = []
+        for lo, hi in ((0, C0), (C0, Cin)):
+            if hi > lo:
+                pc = w[:, :, lo:hi]
+                pad = (-pc.shape[2]) % KC
+                pieces.append(torch.nn.functional.pad(pc, (0, pad)))
+        w = torch.cat(pieces, 2)
+        nch = w.shape[2] // KC
+        w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, (-Co) % BN))  # pad Cout to a multiple of BN
+        nt = w.shape[0] // BN
+        w = w.reshape(nt, BN, 9, nch, KC).permute(0, 3, 2, 1, 4).contiguous()
+        self.w = w.to(dtype)
+        self.bias = bias.detach().float().contiguous()
+        self.Cout, self.C0, self.C1, self.dtype = Co, C0, C1, dtype
+
+
+def conv3x3(x0, cw, x1=None, aff=None, up2=False, want_stats=True, groups=GN_GROUPS):
+    """x0,x1: [B,h,w,C] NHWC; cw: ConvWeight; returns (raw conv output [B,H,W,Cout], GroupNorm partials or None)."""
     B, h, ww, C0 = x0.shape
     H, W = (2 * h, 2 * ww) if up2 else (h, ww)
-    Cout = w.shape[0]
     C1 = x1.shape[-1] if x1 is not None else 0
-    assert w.shape[-1] == C0 + C1, (w.shape, C0, C1)
-    out = torch.empty(B, H, W, Cout, dtype=x0.dtype, device=x0.device)
+    assert (cw.C0, cw.C1) == (C0, C1) and cw.dtype == x0.dtype, ((cw.C0, cw.C1), (C0, C1), cw.dtype, x0.dtype)
+    out = torch.empty(B, H, W, cw.Cout, dtype=x0.dtype, device=x0.device)
     stats = None
     if want_stats:
         tiles = _lib.lib().dig_conv3x3_tiles(H, W)
         stats = torch.empty(B, groups, tiles, 2, dtype=torch.float32, device=x0.device)
-    call("conv3x3", in0=_chk(x0), in1=_chk(x1) if x1 is not None else None, aff0=aff, w=_chk(w), bias=bias, out=out,
-         stats=stats, B=B, H=H, W=W, C0=C0, C1=C1, Cout=Cout, groups=groups, up2=int(up2), dtype=dtype_code(x0.dtype))
+    call("conv3x3", in0=_chk(x0), in1=_chk(x1) if x1 is not None else None, aff0=aff, w=cw.w, bias=cw.bias, out=out,
+         stats=stats, in0_bstride=0, B=B, H=H, W=W, C0=C0, C1=C1, Cout=cw.Cout, groups=groups, up2=int(up2),
+         dtype=dtype_code(x0.dtype))
     return out, stats
 
 

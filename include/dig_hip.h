@@ -35,7 +35,8 @@ const char* dig_last_error(void);
  *   in0/in1 : the two halves of a channel concat [B][Hi][Wi][C0|C1] (in1 may be NULL, C1 = 0);
  *             with up2 != 0 the inputs are [B][H/2][W/2][C] and are read with nearest-x2 addressing.
  *   aff0    : NULL, or [B][C0][2] fp32 (a, b): in0 is read as silu(a*x + b)  (GroupNorm-apply prologue)
- *   w       : [Cout][3][3][C0+C1] (K-major repack of the OIHW weight), bias: [Cout] fp32
+ *   w       : packed [ceil(Cout/BN)][chunks][9 taps][BN][KC] - the per-chunk LDS weight slabs, contiguous, zero padded;
+ *             chunks = ceil(C0/KC) + ceil(C1/KC), (BN, KC) from dig_conv3x3_config(Cout, dtype);   bias: [Cout] fp32
  *   out     : [B][H][W][Cout] raw conv output (+bias)
  *   stats   : NULL, or [B][groups][tiles][2] fp32 per-tile (sum, sumsq) of out over each GroupNorm group,
  *             tiles = dig_conv3x3_tiles(H, W); reduced by dig_gn_finalize (deterministic, no atomics). */
@@ -51,6 +52,7 @@ typedef struct {
     int B, H, W, C0, C1, Cout, groups, up2, dtype;
 } dig_conv3x3_args;
 int dig_conv3x3_tiles(int H, int W);
+int dig_conv3x3_config(int Cout, int dtype, int* BN, int* KC);
 int dig_conv3x3(const dig_conv3x3_args* a, void* stream);
 
 /* ---- batched "NT" GEMM on MFMA: C[z][m][n] = epi( alpha * sum_k A[z][m][k] * Bm[z][n][k] ) -------

@@ -37,14 +37,15 @@ def q(x, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("shape", [(2, 32, 20, 24, 64), (1, 64, 16, 16, 128), (1, 16, 7, 9, 16), (1, 384, 14, 13, 20)])
+@pytest.mark.parametrize("shape", [(2, 32, 20, 24, 64), (1, 64, 16, 16, 128), (1, 16, 7, 9, 16), (1, 384, 14, 13, 20), (1, 48, 33, 17, 32),
+                                   (2, 24, 16, 32, 64), (1, 96, 18, 18, 256)])
 def test_conv3x3_plain(dt, shape):
     B, Ci, H, W, Co = shape
     x, w, b = q(rnd("cx", (B, Ci, H, W)), dt), q(rnd("cw", (Co, Ci, 3, 3), (3.0 / (9 * Ci)) ** 0.5), dt), rnd("cb", (Co,), 0.1)
     ref = F.conv2d(x, w, b, padding=1)
-    wp = w.permute(0, 2, 3, 1).contiguous().to(device=DEV, dtype=dt)
+    cw = ops.ConvWeight(w.to(DEV), b.to(DEV), dt)
     stats_ok = Co % 8 == 0
-    y, st = ops.conv3x3(nhwc(x, dt), wp, b.to(DEV), want_stats=stats_ok)
+    y, st = ops.conv3x3(nhwc(x, dt), cw, want_stats=stats_ok)
     assert (nchw(y) - ref).abs().max() <= tol(dt, ref)
     if stats_ok:
         st = st.cpu().double().sum(2)  # B,G,2
@@ -58,21 +59,21 @@ def test_conv3x3_concat_up2_prologue(dt):
     B, C0, C1, H, W, Co = 2, 32, 16, 10, 12, 32
     x0, x1 = q(rnd("x0", (B, C0, H, W)), dt), q(rnd("x1", (B, C1, H, W)), dt)
     w, b = q(rnd("w", (Co, C0 + C1, 3, 3), 0.1), dt), rnd("b", (Co,), 0.1)
-    wp = w.permute(0, 2, 3, 1).contiguous().to(device=DEV, dtype=dt)
     # concat
     ref = F.conv2d(torch.cat([x0, x1], 1), w, b, padding=1)
-    y, _ = ops.conv3x3(nhwc(x0, dt), wp, b.to(DEV), x1=nhwc(x1, dt))
+    y, _ = ops.conv3x3(nhwc(x0, dt), ops.ConvWeight(w.to(DEV), b.to(DEV), dt, C1=C1), x1=nhwc(x1, dt))
     assert (nchw(y) - ref).abs().max() <= tol(dt, ref)
     # nearest x2 upsample addressing
     w2 = q(rnd("w2", (Co, C0, 3, 3), 0.1), dt)
     ref = F.conv2d(F.interpolate(x0, scale_factor=2, mode="nearest"), w2, b, padding=1)
-    y, _ = ops.conv3x3(nhwc(x0, dt), w2.permute(0, 2, 3, 1).contiguous().to(device=DEV, dtype=dt), b.to(DEV), up2=True, want_stats=False)
+    cw2 = ops.ConvWeight(w2.to(DEV), b.to(DEV), dt)
+    y, _ = ops.conv3x3(nhwc(x0, dt), cw2, up2=True, want_stats=False)
     assert (nchw(y) - ref).abs().max() <= tol(dt, ref)
     # GroupNorm-apply + SiLU prologue
     aff = torch.stack([1.0 + 0.3 * rnd("a", (B, C0)), 0.2 * rnd("bb", (B, C0))], -1)
     xin = F.silu(x0 * aff[..., 0][:, :, None, None] + aff[..., 1][:, :, None, None])
     ref = F.conv2d(q(xin, dt), w2, b, padding=1)
-    y, _ = ops.conv3x3(nhwc(x0, dt), w2.permute(0, 2, 3, 1).contiguous().to(device=DEV, dtype=dt), b.to(DEV), aff=aff.to(DEV).contiguous())
+    y, _ = ops.conv3x3(nhwc(x0, dt), cw2, aff=aff.to(DEV).contiguous())
     assert (nchw(y) - ref).abs().max() <= tol(dt, ref) * (1 if dt == torch.float32 else 2)
 
 

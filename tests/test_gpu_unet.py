@@ -60,8 +60,8 @@ def test_blocks_vs_golden_ops(golden, dt, tl):
         P = {}
         from dig_amd.diffusion import _conv1_pack, _conv3_pack
         p = {"eps": 1e-5, "ss_off": 0}
-        p["w1"], p["b1"] = _conv3_pack(m.block1.proj, dt)
-        p["w2"], p["b2"] = _conv3_pack(m.block2.proj, dt)
+        p["w1"] = _conv3_pack(m.block1.proj, dt)
+        p["w2"] = _conv3_pack(m.block2.proj, dt)
         p["g1"], p["be1"] = m.block1.norm.weight.float(), m.block1.norm.bias.float()
         p["g2"], p["be2"] = m.block2.norm.weight.float(), m.block2.norm.bias.float()
         p["res"] = _conv1_pack(m.res_conv, dt) if cout != 32 else None
