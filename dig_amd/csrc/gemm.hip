@@ -21,15 +21,18 @@ template <typename T> struct GP {
 };
 
 template <typename T, int BN, int BK>
-__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(GP<T> p) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GP<T> p) {
     constexpr int BKP = BK + 8;
     constexpr int V = BK / 8;                 // vectors per row per K-tile
     constexpr int RPP = NTHREADS / V;         // rows covered per pass
     constexpr int APASS = BM / RPP, BPASS = (BN + RPP - 1) / RPP;
     static_assert(BM % RPP == 0, "tile/loader mismatch");
     constexpr int MR = 2, NR = BN / 64;
-    __shared__ __attribute__((aligned(16))) T As[BM * BKP];
-    __shared__ __attribute__((aligned(16))) T Bs[BN * BKP];
+    constexpr int OS = BN + 4;  // fp32 staging row stride of the epilogue
+    constexpr size_t MAIN_BYTES = (size_t)(BM + BN) * BKP * sizeof(T), EPI_BYTES = (size_t)64 * OS * sizeof(float);
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES];
+    T* As = reinterpret_cast<T*>(smem_raw);
+    T* Bs = As + BM * BKP;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hf = lane >> 5;
@@ -138,38 +141,86 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(GP<T> p) {
         }
     }
 
-    // ---- epilogue
+    // ---- epilogue: the fp32 tile goes through LDS (64 rows at a time) so that every global access of the epilogue
+    // (bias, GroupNorm source, residual, output) is a 16-byte vector of 8 consecutive columns.
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last MFMA retired before the accumulators are read
     const long long coff = zo * p.sc_o + zi * p.sc_i;
     const T* R = p.res ? p.res + zo * p.sr_o + zi * p.sr_i : nullptr;
+    float* ot = reinterpret_cast<float*>(smem_raw);
+    const bool vec = p.c_mode == 0 && (p.ldc % 8) == 0 && (coff % 8) == 0 && (!R || (p.ldr % 8) == 0) && (!p.gsrc || (p.ldg % 8) == 0) &&
+                     (p.N % 8) == 0;
 #pragma unroll
-    for (int nr = 0; nr < NR; nr++) {
-        const int n = n0 + wn * (BN / 2) + nr * 32 + r;
-        if (n >= p.N) continue;
-        const float bias = p.bias ? p.bias[n] : 0.f;
+    for (int mr = 0; mr < MR; mr++) {
 #pragma unroll
-        for (int mr = 0; mr < MR; mr++) {
+        for (int nr = 0; nr < NR; nr++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int m = m0 + wm * 64 + mr * 32 + acc_row(e, lane);
-                if (m >= p.M) continue;
-                float v = acc[mr][nr][e] * p.alpha + bias;
-                if (p.gsrc) {
-                    const int img = m / p.rows_per_img;
-                    const float* ga = p.gaff + ((size_t)img * p.N + n) * 2;
-                    v += silu_f(ga[0] * to_f32<T>(p.gsrc[(size_t)m * p.ldg + n]) + ga[1]);
+            for (int e = 0; e < 16; e++)
+                ot[(wm * 32 + acc_row(e, lane)) * OS + wn * (BN / 2) + nr * 32 + r] = acc[mr][nr][e] * p.alpha;
+        __syncthreads();
+        for (int idx = tid; idx < 64 * (BN / 8); idx += NTHREADS) {
+            const int rl = idx / (BN / 8), v8 = idx - rl * (BN / 8);
+            const int m = m0 + (rl >> 5) * 64 + mr * 32 + (rl & 31);
+            const int n = n0 + v8 * 8;
+            if (m >= p.M || n >= p.N) continue;
+            const float* sp = ot + rl * OS + v8 * 8;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = sp[j];
+            const int nj = p.N - n < 8 ? p.N - n : 8;
+            if (p.bias)
+                for (int j = 0; j < nj; j++) v[j] += p.bias[n + j];
+            if (p.gsrc) {
+                const int img = m / p.rows_per_img;
+                const float* ga = p.gaff + ((size_t)img * p.N + n) * 2;
+                if (vec) {
+                    Frag<T> g;
+                    frag_load<T>(g, p.gsrc + (size_t)m * p.ldg + n);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v[j] += silu_f(ga[2 * j] * frag_get<T>(g, j) + ga[2 * j + 1]);
+                } else {
+                    for (int j = 0; j < nj; j++) v[j] += silu_f(ga[2 * j] * to_f32<T>(p.gsrc[(size_t)m * p.ldg + n + j]) + ga[2 * j + 1]);
                 }
-                if (p.gelu) v = gelu_erf_f(v);
-                if (R) v += to_f32<T>(R[(size_t)m * p.ldr + n]);
-                size_t idx;
-                if (p.c_mode == 0) idx = (size_t)m * p.ldc + n;
-                else {
-                    const int bi = m / p.hw, pix = m - bi * p.hw;
-                    idx = ((size_t)bi * p.N + n) * p.hw + pix;
+            }
+            if (p.gelu) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = gelu_erf_f(v[j]);
+            }
+            if (R) {
+                if (vec) {
+                    Frag<T> g;
+                    frag_load<T>(g, R + (size_t)m * p.ldr + n);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v[j] += frag_get<T>(g, j);
+                } else {
+                    for (int j = 0; j < nj; j++) v[j] += to_f32<T>(R[(size_t)m * p.ldr + n + j]);
                 }
-                if (p.out_f32) ((float*)p.c)[coff + idx] = v;
-                else ((T*)p.c)[coff + idx] = from_f32<T>(v);
+            }
+            if (vec) {
+                const size_t idxo = coff + (size_t)m * p.ldc + n;
+                if (p.out_f32) {
+                    float* d = (float*)p.c + idxo;
+                    *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                } else {
+                    Frag<T> f;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) frag_set<T>(f, j, v[j]);
+                    frag_store<T>(f, (T*)p.c + idxo);
+                }
+            } else {
+                for (int j = 0; j < nj; j++) {
+                    size_t idxo;
+                    if (p.c_mode == 0) idxo = (size_t)m * p.ldc + n + j;
+                    else {
+                        const int bi = m / p.hw, pix = m - bi * p.hw;
+                        idxo = ((size_t)bi * p.N + n + j) * p.hw + pix;
+                    }
+                    if (p.out_f32) ((float*)p.c)[coff + idxo] = v[j];
+                    else ((T*)p.c)[coff + idxo] = from_f32<T>(v[j]);
+                }
             }
         }
+        __syncthreads();
     }
 }
 
