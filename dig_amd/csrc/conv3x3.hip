@@ -105,7 +105,11 @@ __global__ __launch_bounds__(NTHREADS, CONV_WAVES) void conv3x3_kernel(Params<T>
             const int hy = pix / HALO, hx = pix - hy * HALO;
             const int Y = ty0 + hy - 1, X = tx0 + hx - 1;
             const bool ok = (idx < HALO * HALO * V) && chv && Y >= 0 && Y < p.H && X >= 0 && X < p.W;
+#ifdef ABL_NO_GLOAD
+            if (ok && p.B == 12345) {
+#else
             if (ok) {
+#endif
                 const int sy = p.up2 ? Y >> 1 : Y, sx = p.up2 ? X >> 1 : X;
                 frag_load<T>(hreg[i], src + (size_t)b * bs + ((size_t)sy * Ws + sx) * Cp + ch);
                 hok |= 1u << i;
@@ -117,7 +121,13 @@ __global__ __launch_bounds__(NTHREADS, CONV_WAVES) void conv3x3_kernel(Params<T>
 #pragma unroll
         for (int i = 0; i < NW; i++) {
             const int idx = tid + i * NTHREADS;
+#ifdef ABL_NO_GLOAD
+            if (idx < 9 * BN * V && p.B == 12345) frag_load<T>(wreg[i], slab + (size_t)idx * 8);
+#elif defined(ABL_NO_WLOAD)
+            if (idx < 9 * BN * V && ci == 0) frag_load<T>(wreg[i], slab + (size_t)idx * 8);
+#else
             if (idx < 9 * BN * V) frag_load<T>(wreg[i], slab + (size_t)idx * 8);
+#endif
         }
     };
     // registers -> LDS (GroupNorm-apply + SiLU prologue applied here, once per input element)
@@ -183,7 +193,13 @@ __global__ __launch_bounds__(NTHREADS, CONV_WAVES) void conv3x3_kernel(Params<T>
 #pragma unroll
                 for (int mr = 0; mr < MR; mr++)
 #pragma unroll
-                    for (int nr = 0; nr < NR; nr++) mma16<T>(acc[mr][nr], fa[mr], fb[nr]);
+                    for (int nr = 0; nr < NR; nr++) {
+#ifndef ABL_NO_MFMA
+                        mma16<T>(acc[mr][nr], fa[mr], fb[nr]);
+#else
+                        acc[mr][nr][0] += frag_get<T>(fa[mr], 0) * frag_get<T>(fb[nr], 0);
+#endif
+                    }
             }
         }
     }
@@ -235,7 +251,11 @@ __global__ __launch_bounds__(NTHREADS, CONV_WAVES) void conv3x3_kernel(Params<T>
                     const f32x4 lo = *reinterpret_cast<const f32x4*>(sp), hi = *reinterpret_cast<const f32x4*>(sp + 4);
                     frag_set<T>(f, 0, lo[0]); frag_set<T>(f, 1, lo[1]); frag_set<T>(f, 2, lo[2]); frag_set<T>(f, 3, lo[3]);
                     frag_set<T>(f, 4, hi[0]); frag_set<T>(f, 5, hi[1]); frag_set<T>(f, 6, hi[2]); frag_set<T>(f, 7, hi[3]);
+#ifndef ABL_NO_STORE
                     frag_store<T>(f, dst);
+#else
+                    if (lo[0] == 123.456f) frag_store<T>(f, dst);
+#endif
                 } else {
                     for (int j = 0; j < 8 && n + j < p.Cout; j++) dst[j] = from_f32<T>(sp[j]);
                 }

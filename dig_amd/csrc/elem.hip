@@ -109,11 +109,37 @@ template <typename T, int G> __global__ void rmsnorm_kernel(dig_rmsnorm_args a) 
     }
 }
 
-// softmax over contiguous rows; one block per row
-template <typename TI, typename TO> __global__ void row_softmax_kernel(const TI* in, TO* out, int n) {
+// softmax over contiguous rows; one block per row.  Rows of up to 256*RPT elements are held in registers, so the
+// row is read from HBM exactly once (fp32 logits in, T probabilities out); longer rows fall back to three passes.
+template <typename TI, typename TO, int RPT> __global__ __launch_bounds__(256) void row_softmax_kernel(const TI* in, TO* out, int n) {
     __shared__ float red[32];
     const TI* x = in + (size_t)blockIdx.x * n;
     TO* y = out + (size_t)blockIdx.x * n;
+    if (n <= 256 * RPT) {
+        float v[RPT];
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+            const int i = threadIdx.x + k * 256;
+            v[k] = i < n ? (float)x[i] : -INFINITY;
+            m = fmaxf(m, v[k]);
+        }
+        m = block_max(m, red);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+            v[k] = __expf(v[k] - m);
+            s += v[k];
+        }
+        s = block_sum(s, red);
+        const float inv = 1.0f / s;
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+            const int i = threadIdx.x + k * 256;
+            if (i < n) y[i] = (TO)(v[k] * inv);
+        }
+        return;
+    }
     float m = -INFINITY;
     for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, (float)x[i]);
     m = block_max(m, red);
@@ -309,10 +335,10 @@ extern "C" int dig_row_softmax(const dig_row_softmax_args* a, void* stream_) {
     DIG_CHECK(a->rows < 2147483647LL, DIG_EINVAL, "row_softmax: too many rows");
     const dim3 g((unsigned)a->rows), b(256);
     if (a->dtype == DIG_BF16) {
-        if (a->in_f32) hipLaunchKernelGGL((row_softmax_kernel<float, bf16>), g, b, 0, stream, (const float*)a->in, (bf16*)a->out, a->n);
-        else hipLaunchKernelGGL((row_softmax_kernel<bf16, bf16>), g, b, 0, stream, (const bf16*)a->in, (bf16*)a->out, a->n);
+        if (a->in_f32) hipLaunchKernelGGL((row_softmax_kernel<float, bf16, 8>), g, b, 0, stream, (const float*)a->in, (bf16*)a->out, a->n);
+        else hipLaunchKernelGGL((row_softmax_kernel<bf16, bf16, 8>), g, b, 0, stream, (const bf16*)a->in, (bf16*)a->out, a->n);
     } else {
-        hipLaunchKernelGGL((row_softmax_kernel<float, float>), g, b, 0, stream, (const float*)a->in, (float*)a->out, a->n);
+        hipLaunchKernelGGL((row_softmax_kernel<float, float, 8>), g, b, 0, stream, (const float*)a->in, (float*)a->out, a->n);
     }
     DIG_LAUNCH_CHECK("row_softmax");
     return DIG_OK;

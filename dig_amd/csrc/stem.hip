@@ -14,79 +14,107 @@ constexpr int TH = 8, TW = 16;            // output tile
 constexpr int HH = TH + 6, HW_ = TW + 6;  // halo 14 x 22
 constexpr int KPAD = 160, KROW = KPAD + 8;
 
+template <typename T, int HALF> __device__ __forceinline__ void build_rows(const float* hb, T* dst) {
+#pragma unroll
+    for (int v = 0; v < 10; v++) {
+        Frag<T> f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int k = (HALF * 10 + v) * 8 + j;  // compile-time after unrolling
+            float x = 0.f;
+            if (k < 147) {
+                const int tap = k / 3, c = k - tap * 3, ky = tap / 7, kx = tap - ky * 7;
+                x = hb[(c * HH + ky) * (HW_ + 1) + kx];
+            }
+            frag_set<T>(f, j, x);
+        }
+        frag_store<T>(f, dst + (HALF * 10 + v) * 8);
+    }
+}
+
 template <typename T> __global__ __launch_bounds__(256) void stem_kernel(dig_stem_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* halo = reinterpret_cast<float*>(smem);                    // [3][14][23] fp32
     T* Ap = reinterpret_cast<T*>(smem + 3 * HH * (HW_ + 1) * 4 + 8); // [128][KROW]  (offset keeps 16-B alignment: 3864+8)
     T* Wp = Ap + 128 * KROW;                                         // [Cout][KROW]
+    float* ot = reinterpret_cast<float*>(Ap);                        // epilogue staging [128][36] fp32, aliases Ap
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
-    const int b = blockIdx.x / (tiles_x * tiles_y), tile = blockIdx.x % (tiles_x * tiles_y);
-    const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
-    const long long t = a.t[b];
-    const float ca = a.sqrt_ac[t], cs = a.sqrt_1mac[t];
+    const int ntiles = a.B * tiles_x * tiles_y;
     const size_t HW = (size_t)a.H * a.W;
-    for (int i = tid; i < 3 * HH * HW_; i += 256) {
-        const int c = i / (HH * HW_), rem = i % (HH * HW_), hy = rem / HW_, hx = rem % HW_;
-        const int Y = ty0 + hy - 3, X = tx0 + hx - 3;
-        float v = 0.f;
-        if (Y >= 0 && Y < a.H && X >= 0 && X < a.W) {
-            const size_t idx = ((size_t)b * 3 + c) * HW + (size_t)Y * a.W + X;
-            const float x0 = a.pre_scale[c] * a.img[idx] + a.pre_shift[c];
-            v = ca * x0 + cs * a.noise[idx];
-            if (a.x_t && hy >= 3 && hy < 3 + TH && hx >= 3 && hx < 3 + TW) a.x_t[idx] = v;
-        }
-        halo[(c * HH + hy) * (HW_ + 1) + hx] = v;
+    // weight panel, once per (persistent) block: w is [Cout][160] in T, copied as 16-byte vectors
+    for (int i = tid; i < a.Cout * (KPAD / 8); i += 256) {
+        const int n = i / (KPAD / 8), v = i - n * (KPAD / 8);
+        Frag<T> f;
+        frag_load<T>(f, (const T*)a.w + (size_t)n * KPAD + v * 8);
+        frag_store<T>(f, Wp + n * KROW + v * 8);
     }
-    // weight panel: w is [147][Cout] fp32 (tap-major); transpose into [Cout][KROW] T with zero K padding
-    for (int i = tid; i < a.Cout * KPAD; i += 256) {
-        const int n = i / KPAD, k = i - n * KPAD;
-        Wp[n * KROW + k] = from_f32<T>(k < 147 ? a.w[k * a.Cout + n] : 0.f);
-    }
-    __syncthreads();
-    // im2col panel: 2 threads per pixel, each builds 10 of the 20 8-element vectors of its row
-    {
-        const int pix = tid >> 1, half = tid & 1;
-        const int py = pix / TW, px = pix % TW;
-#pragma unroll 2
-        for (int v = 0; v < 10; v++) {
-            const int k0 = (half * 10 + v) * 8;
-            Frag<T> f;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int k = k0 + j;
-                float x = 0.f;
-                if (k < 147) {
-                    const int tap = k / 3, c = k - tap * 3, ky = tap / 7, kx = tap - ky * 7;
-                    x = halo[(c * HH + py + ky) * (HW_ + 1) + px + kx];
-                }
-                frag_set<T>(f, j, x);
+    for (int tidx = blockIdx.x; tidx < ntiles; tidx += gridDim.x) {
+        const int b = tidx / (tiles_x * tiles_y), tile = tidx % (tiles_x * tiles_y);
+        const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
+        const long long t = a.t[b];
+        const float ca = a.sqrt_ac[t], cs = a.sqrt_1mac[t];
+        __syncthreads();  // previous tile's staging reads are done
+        for (int i = tid; i < 3 * HH * HW_; i += 256) {
+            const int c = i / (HH * HW_), rem = i % (HH * HW_), hy = rem / HW_, hx = rem % HW_;
+            const int Y = ty0 + hy - 3, X = tx0 + hx - 3;
+            float v = 0.f;
+            if (Y >= 0 && Y < a.H && X >= 0 && X < a.W) {
+                const size_t idx = ((size_t)b * 3 + c) * HW + (size_t)Y * a.W + X;
+                const float x0 = a.pre_scale[c] * a.img[idx] + a.pre_shift[c];
+                v = ca * x0 + cs * a.noise[idx];
+                if (a.x_t && hy >= 3 && hy < 3 + TH && hx >= 3 && hx < 3 + TW) a.x_t[idx] = v;
             }
-            frag_store<T>(f, Ap + pix * KROW + k0);
+            halo[(c * HH + hy) * (HW_ + 1) + hx] = v;
         }
-    }
-    __syncthreads();
-    // MFMA: wave w owns pixels 32w..32w+31 (tile rows 2w, 2w+1) x all Cout, 32 channels at a time
-    for (int n0 = 0; n0 < a.Cout; n0 += 32) {
-        f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; e++) acc[e] = 0.f;
-        const bool nv = n0 + r < a.Cout;
-#pragma unroll
-        for (int kk = 0; kk < KPAD / 16; kk++) {
-            Frag<T> fa, fb;
-            frag_load<T>(fa, Ap + (wave * 32 + r) * KROW + kk * 16 + hf * 8);
-            if (nv) frag_load<T>(fb, Wp + (n0 + r) * KROW + kk * 16 + hf * 8);
-            else frag_zero<T>(fb);
-            mma16<T>(acc, fa, fb);
+        __syncthreads();
+        // im2col panel: 2 threads per pixel, each builds 10 of the 20 8-element vectors of its row.  The K range of a
+        // thread is a compile-time constant (template on the half) so tap/channel decoding costs no integer division.
+        {
+            const int pix = tid >> 1;
+            const int py = pix / TW, px = pix % TW;
+            const float* hb = halo + py * (HW_ + 1) + px;
+            T* dst = Ap + pix * KROW;
+            if (tid & 1) build_rows<T, 1>(hb, dst);
+            else build_rows<T, 0>(hb, dst);
         }
-        const float bias = nv ? a.bias[n0 + r] : 0.f;
+        __syncthreads();
+        // MFMA: wave w owns pixels 32w..32w+31 (tile rows 2w, 2w+1); A fragments are read once and kept in registers
+        Frag<T> fa[KPAD / 16];
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const int pix = wave * 32 + acc_row(e, lane);
-            const int Y = ty0 + pix / TW, X = tx0 + pix % TW;
-            if (nv && Y < a.H && X < a.W)
-                ((T*)a.out)[(((size_t)b * a.H + Y) * a.W + X) * a.Cout + n0 + r] = from_f32<T>(acc[e] + bias);
+        for (int kk = 0; kk < KPAD / 16; kk++) frag_load<T>(fa[kk], Ap + (wave * 32 + r) * KROW + kk * 16 + hf * 8);
+        __syncthreads();  // Ap may now be overwritten by the output staging
+        for (int n0 = 0; n0 < a.Cout; n0 += 32) {
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[e] = 0.f;
+            const bool nv = n0 + r < a.Cout;
+#pragma unroll
+            for (int kk = 0; kk < KPAD / 16; kk++) {
+                Frag<T> fb;
+                if (nv) frag_load<T>(fb, Wp + (n0 + r) * KROW + kk * 16 + hf * 8);
+                else frag_zero<T>(fb);
+                mma16<T>(acc, fa[kk], fb);
+            }
+            const float bias = nv ? a.bias[n0 + r] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; e++) ot[(wave * 32 + acc_row(e, lane)) * 36 + r] = acc[e] + bias;
+            __syncthreads();
+            for (int idx = tid; idx < 128 * 4; idx += 256) {
+                const int pix = idx >> 2, v8 = idx & 3;
+                const int Y = ty0 + pix / TW, X = tx0 + pix % TW;
+                const int n = n0 + v8 * 8;
+                if (Y < a.H && X < a.W && n < a.Cout) {
+                    const float* sp = ot + pix * 36 + v8 * 8;
+                    Frag<T> f;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) frag_set<T>(f, j, sp[j]);
+                    frag_store<T>(f, (T*)a.out + (((size_t)b * a.H + Y) * a.W + X) * a.Cout + n);
+                }
+            }
+            __syncthreads();
         }
     }
 }
@@ -99,7 +127,8 @@ template <typename T> int launch(const dig_stem_args* a, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute((const void*)stem_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "qsample_stem: cannot raise dynamic LDS: %s", hipGetErrorString(e));
     const int tiles = cdiv(a->W, TW) * cdiv(a->H, TH);
-    hipLaunchKernelGGL(stem_kernel<T>, dim3(a->B * tiles), dim3(256), lds, stream, *a);
+    const int total = a->B * tiles;
+    hipLaunchKernelGGL(stem_kernel<T>, dim3(total < 1024 ? total : 1024), dim3(256), lds, stream, *a);
     DIG_LAUNCH_CHECK("qsample_stem");
     return DIG_OK;
 }

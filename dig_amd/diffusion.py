@@ -213,7 +213,8 @@ def _conv1_pack(conv, dt):
 def _pack_unet(u, dt):
     f32 = lambda t: t.detach().float().contiguous()
     P = {"dtype": dt}
-    P["stem_w"] = f32(u.init_conv.weight.permute(2, 3, 1, 0).reshape(147, -1))  # [tap][c][Cout]
+    sw = u.init_conv.weight.detach().float().permute(0, 2, 3, 1).reshape(u.dim, 147)  # [Cout][(ky,kx,c)]
+    P["stem_w"] = torch.nn.functional.pad(sw, (0, 13)).contiguous().to(dt)  # K padded to 160
     P["stem_b"] = f32(u.init_conv.bias)
     P["t1"] = (f32(u.time_mlp[1].weight), f32(u.time_mlp[1].bias))
     P["t3"] = (f32(u.time_mlp[3].weight), f32(u.time_mlp[3].bias))
@@ -314,7 +315,7 @@ def _linear_attention(p, x):
     kmax = torch.empty(B * hid, dtype=torch.float32, device=x.device)
     call("row_max", **{"in": kvT}, out=kmax, rows=B * hid, group_stride=2 * hid * n, group_rows=hid, n=n, dtype=dtype_code(dt))
     chunks = (n + 63) // 64
-    splits = max(1, min(64, chunks // 8))
+    splits = max(1, min(32, chunks // 8))
     part = torch.empty(B * heads, splits, 32, 32, dtype=torch.float32, device=x.device)
     ksum = torch.empty(B * heads, splits, 32, dtype=torch.float32, device=x.device)
     esz = kvT.element_size()

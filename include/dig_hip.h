@@ -176,14 +176,15 @@ int dig_la_finalize(const dig_la_finalize_args* a, void* stream);
  * Replaces denormforDiff/normalize (model.py:499-508, ddp.py:82-83), extract + q_sample (ddp.py:452-455,
  * 853-860) and init_conv (ddp.py:296,388).  img, noise: NCHW fp32 [B][3][H][W];
  *   x0 = pre_scale[c]*img + pre_shift[c];  x_t = ca[t[b]]*x0 + cs[t[b]]*noise  (written to x_t, NCHW fp32, if non-NULL)
- *   out = conv7x7(x_t) + bias  as NHWC dtype [B][H][W][Cout] (Cout % 16 == 0);  w: [49 taps][3][Cout] fp32. */
+ *   out = conv7x7(x_t) + bias  as NHWC dtype [B][H][W][Cout] (Cout % 8 == 0);
+ *   w: [Cout][160] in dtype, k = (ky*7+kx)*3 + c for k < 147, zero for 147 <= k < 160 (the kernel's LDS weight panel). */
 typedef struct {
     const float* img;
     const float* noise;
     const long long* t;
     const float* sqrt_ac;
     const float* sqrt_1mac;
-    const float* w;
+    const void* w;
     const float* bias;
     float* x_t;
     void* out;
