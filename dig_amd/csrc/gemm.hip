@@ -17,7 +17,7 @@ template <typename T> struct GP {
     long long sa_o, sa_i, sa1_o, sa1_i, sb_o, sb_i, sc_o, sc_i, sr_o, sr_i;
     int M, N, K, K0, lda0, lda1, ldb, ldc, ldr, ldg;
     int z_inner, a_mode, Ho, Wo, Cu, c_mode, hw, rows_per_img, gelu, out_f32;
-    float alpha;
+    float alpha, gsm_scale;
 };
 
 template <typename T, int BN, int BK>
@@ -185,6 +185,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(GP<T> p) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) v[j] = gelu_erf_f(v[j]);
             }
+            if (p.gsm_scale != 0.f) {  // softmax over each aligned group of 32 columns (4 adjacent lanes x 8), times scale
+                float mx = v[0];
+#pragma unroll
+                for (int j = 1; j < 8; j++) mx = fmaxf(mx, v[j]);
+                mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+                float sm = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    v[j] = __expf(v[j] - mx);
+                    sm += v[j];
+                }
+                sm += __shfl_xor(sm, 1, 64);
+                sm += __shfl_xor(sm, 2, 64);
+                const float inv = p.gsm_scale / sm;
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] *= inv;
+            }
             if (R) {
                 if (vec) {
                     Frag<T> g;
@@ -235,7 +253,7 @@ template <typename T, int BN, int BK> int launch(const dig_gemm_args* a, hipStre
     p.z_inner = a->z_inner > 0 ? a->z_inner : 1;
     p.a_mode = a->a_mode; p.Ho = a->unsh_Ho; p.Wo = a->unsh_Wo; p.Cu = a->unsh_C;
     p.c_mode = a->c_mode; p.hw = a->hw > 0 ? a->hw : 1; p.rows_per_img = a->rows_per_img > 0 ? a->rows_per_img : 1;
-    p.gelu = a->gelu; p.out_f32 = a->out_f32; p.alpha = a->alpha;
+    p.gelu = a->gelu; p.out_f32 = a->out_f32; p.alpha = a->alpha; p.gsm_scale = a->gsm_scale;
     dim3 grid(cdiv(a->M, BM), cdiv(a->N, BN), a->batch > 0 ? a->batch : 1);
     hipLaunchKernelGGL((gemm_nt_kernel<T, BN, BK>), grid, dim3(NTHREADS), 0, stream, p);
     DIG_LAUNCH_CHECK("gemm_nt");
@@ -263,6 +281,7 @@ extern "C" int dig_gemm_nt(const dig_gemm_args* a, void* stream_) {
     DIG_CHECK(a->c_mode == 0 || (a->c_mode == 1 && a->hw > 0 && a->M % a->hw == 0), DIG_EINVAL, "gemm_nt: bad NCHW store geometry");
     DIG_CHECK(!a->gsrc || (a->gaff && a->rows_per_img > 0), DIG_EINVAL, "gemm_nt: gsrc needs gaff and rows_per_img");
     DIG_CHECK(a->batch <= 65535, DIG_EINVAL, "gemm_nt: batch too large");
+    DIG_CHECK(a->gsm_scale == 0.f || (a->N % 32 == 0 && a->c_mode == 0), DIG_EINVAL, "gemm_nt: group softmax needs N %% 32 == 0");
     if (a->dtype == DIG_BF16) {
         if (a->N > 64) return launch<bf16, 128, 32>(a, stream);
         return launch<bf16, 64, 32>(a, stream);

@@ -71,7 +71,7 @@ template <typename T> __global__ void la_finalize_kernel(dig_la_finalize_args a)
             s += a.part[((size_t)bh * a.splits + sp) * 1024 + i];
             ks += a.ksum[((size_t)bh * a.splits + sp) * 32 + d];
         }
-        out[i] = from_f32<T>(a.scale * s / ks);
+        out[a.transposed ? (d * 32 + (i >> 5)) : i] = from_f32<T>(a.scale * s / ks);
     }
 }
 

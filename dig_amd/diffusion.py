@@ -308,8 +308,8 @@ def _linear_attention(p, x):
     dt = x.dtype
     assert n % 8 == 0, "H*W must be a multiple of 8 at every linear-attention level"
     xn = ops.rmsnorm(x, p["g"])
-    q = ops.linear_rows(xn, p["wq"])  # [B,H,W,hid] pixel-major
-    ops.group_softmax32_(q, 32 ** -0.5)
+    # q projection with q.softmax(dim=-2) * scale fused into the GEMM epilogue (ddp.py:224,227)
+    q = ops.linear_rows(xn, p["wq"], gsm_scale=32 ** -0.5)  # [B,H,W,hid] pixel-major
     kvT = torch.empty(B, 2 * hid, n, dtype=dt, device=x.device)  # channel-major k | v
     ops.gemm_nt(p["wkv"], xn, kvT, 2 * hid, n, C, dtype=dt, batch=B, sb=(n * C, 0), sc=(2 * hid * n, 0))
     kmax = torch.empty(B * hid, dtype=torch.float32, device=x.device)
@@ -322,12 +322,16 @@ def _linear_attention(p, x):
     call("la_context", k=kvT.data_ptr(), v=kvT.data_ptr() + hid * n * esz, kmax=kmax, part=part, ksum=ksum,
          b_stride_k=2 * hid * n, h_stride_k=32 * n, b_stride_v=2 * hid * n, h_stride_v=32 * n,
          B=B, heads=heads, n=n, splits=splits, dtype=dtype_code(dt))
-    ctxT = torch.empty(B * heads, 32, 32, dtype=dt, device=x.device)
-    call("la_finalize", part=part, ksum=ksum, ctxT=ctxT, BH=B * heads, splits=splits, dtype=dtype_code(dt), scale=1.0)
-    att = torch.empty(B, H, W, hid, dtype=dt, device=x.device)
-    ops.gemm_nt(q, ctxT, att, n, 32, 32, dtype=dt, lda0=hid, ldb=32, ldc=hid, batch=B * heads, z_inner=heads,
-                sa=(n * hid, 32), sb=(heads * 1024, 1024), sc=(n * hid, 32))
-    y = ops.linear_rows(att, p["wo"], bias=p["bo"])
+    ctx = torch.empty(B * heads, 32, 32, dtype=dt, device=x.device)  # [bh][d][e]
+    call("la_finalize", part=part, ksum=ksum, ctxT=ctx, BH=B * heads, splits=splits, dtype=dtype_code(dt), transposed=1, scale=1.0)
+    # second einsum (ddp.py:231) and to_out conv folded into ONE per-image matrix:  y = Wout . blockdiag(ctx^T) . q = M_b . q,
+    # M_b[c][h*32+d] = sum_e Wout[c][h*32+e] * ctx[h][d][e]   (tiny batched GEMM), then y = q @ M_b^T + bias.
+    dim = p["wo"].shape[0]
+    Mb = torch.empty(B, dim, hid, dtype=dt, device=x.device)
+    ops.gemm_nt(p["wo"], ctx, Mb, dim, 32, 32, dtype=dt, lda0=hid, ldb=32, ldc=hid, batch=B * heads, z_inner=heads,
+                sa=(0, 32), sb=(heads * 1024, 1024), sc=(dim * hid, 32))
+    y = torch.empty(B, H, W, dim, dtype=dt, device=x.device)
+    ops.gemm_nt(q, Mb, y, n, dim, hid, dtype=dt, bias=p["bo"], batch=B, sa=(n * hid, 0), sb=(dim * hid, 0), sc=(n * dim, 0))
     return ops.rmsnorm(y, p["g2"], res=x)
 
 

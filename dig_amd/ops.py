@@ -87,7 +87,7 @@ def rmsnorm(x, g, res=None):
 
 def gemm_nt(a0, b, c, M, N, K, *, dtype, a1=None, K0=0, lda0=None, lda1=0, ldb=None, ldc=None, bias=None, res=None, ldr=0,
             gsrc=None, gaff=None, ldg=0, rows_per_img=0, alpha=1.0, gelu=False, out_f32=False, batch=1, z_inner=1,
-            sa=(0, 0), sa1=(0, 0), sb=(0, 0), sc=(0, 0), sr=(0, 0), unshuffle=None, nchw_hw=0):
+            sa=(0, 0), sa1=(0, 0), sb=(0, 0), sc=(0, 0), sr=(0, 0), unshuffle=None, nchw_hw=0, gsm_scale=0.0):
     """Raw access to dig_gemm_nt; strides are in elements.  a0/b/c may be tensors or (tensor, element_offset)."""
 
     def ptr(x):
@@ -103,7 +103,7 @@ def gemm_nt(a0, b, c, M, N, K, *, dtype, a1=None, K0=0, lda0=None, lda1=0, ldb=N
               sr_o=sr[0], sr_i=sr[1], M=M, N=N, K=K, K0=K0, lda0=lda0 if lda0 is not None else K, lda1=lda1,
               ldb=ldb if ldb is not None else K, ldc=ldc if ldc is not None else N, ldr=ldr, ldg=ldg, batch=batch,
               z_inner=z_inner, a_mode=0, unsh_Ho=0, unsh_Wo=0, unsh_C=0, c_mode=0, hw=0, rows_per_img=rows_per_img,
-              gelu=int(gelu), out_f32=int(out_f32), dtype=dtype_code(dtype), alpha=float(alpha))
+              gelu=int(gelu), out_f32=int(out_f32), dtype=dtype_code(dtype), alpha=float(alpha), gsm_scale=float(gsm_scale))
     if unshuffle is not None:
         kw.update(a_mode=1, unsh_Ho=unshuffle[0], unsh_Wo=unshuffle[1], unsh_C=unshuffle[2])
     if nchw_hw:
@@ -111,7 +111,7 @@ def gemm_nt(a0, b, c, M, N, K, *, dtype, a1=None, K0=0, lda0=None, lda1=0, ldb=N
     call("gemm_nt", **kw)
 
 
-def linear_rows(x, w, bias=None, res=None, gelu=False, out_f32=False, x1=None, gsrc=None, gaff=None, rows_per_img=0):
+def linear_rows(x, w, bias=None, res=None, gelu=False, out_f32=False, x1=None, gsrc=None, gaff=None, rows_per_img=0, gsm_scale=0.0):
     """y[rows, N] = [x | x1] @ w^T (+bias, +silu(gn(gsrc)), gelu, +res).  x: [..., K0] contiguous; w: [N, K]."""
     K0 = x.shape[-1]
     K1 = x1.shape[-1] if x1 is not None else 0
@@ -122,7 +122,7 @@ def linear_rows(x, w, bias=None, res=None, gelu=False, out_f32=False, x1=None, g
     y = torch.empty(*x.shape[:-1], N, dtype=odt, device=x.device)
     gemm_nt(_chk(x), _chk(w), y, M, N, K, dtype=x.dtype, a1=_chk(x1) if x1 is not None else None, K0=K0, lda0=K0, lda1=K1,
             bias=bias, res=_chk(res) if res is not None else None, ldr=N, gsrc=_chk(gsrc) if gsrc is not None else None,
-            gaff=gaff, ldg=N, rows_per_img=rows_per_img, gelu=gelu, out_f32=out_f32)
+            gaff=gaff, ldg=N, rows_per_img=rows_per_img, gelu=gelu, out_f32=out_f32, gsm_scale=gsm_scale)
     return y
 
 

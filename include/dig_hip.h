@@ -83,6 +83,7 @@ typedef struct {
     int c_mode, hw, rows_per_img;
     int gelu, out_f32, dtype;
     float alpha;
+    float gsm_scale; /* != 0: after bias, softmax over every aligned group of 32 columns, times gsm_scale (q.softmax(dim=-2)*scale, ddp.py:224,227) */
 } dig_gemm_args;
 int dig_gemm_nt(const dig_gemm_args* a, void* stream);
 
@@ -168,6 +169,7 @@ typedef struct {
     const float* ksum;
     void* ctxT;
     int BH, splits, dtype;
+    int transposed; /* 0: ctxT[bh][e][d]; 1: ctx[bh][d][e] */
     float scale;
 } dig_la_finalize_args;
 int dig_la_finalize(const dig_la_finalize_args* a, void* stream);
