@@ -14,30 +14,34 @@
 
 namespace {
 
-constexpr int TILE = 16;           // 16x16 output pixels per block
-constexpr int HALO = TILE + 2;     // 18
-constexpr int NTHREADS = 256;
-#ifndef CONV_WAVES
-#define CONV_WAVES 2
-#endif
+constexpr int TILE_W = 16;          // tile width; tile height = 4 rows per pixel-group wave
+constexpr int HALO_W = TILE_W + 2;  // 18
 #ifndef CONV_PF64
 #define CONV_PF64 true
 #endif
 #ifndef CONV_PF128
 #define CONV_PF128 false
 #endif
+#ifndef CONV_WNG128
+#define CONV_WNG128 1
+#endif
+#ifndef CONV_WPG64
+#define CONV_WPG64 4
+#endif
 
-template <typename T, int KC> struct ConvCfg {
+// WPG = waves along pixels (each owns 4 tile rows = 64 pixels), WNG = waves along output channels
+template <typename T, int KC, int WPG> struct ConvCfg {
     static constexpr int KCP = KC + 8;  // padded per-pixel channel stride (elements)
-    static constexpr int HROW = ((HALO * KCP * (int)sizeof(T) + 255) / 256) * 256 / (int)sizeof(T);
-    static constexpr int HALO_ELEMS = HALO * HROW;
+    static constexpr int TILE_H = 4 * WPG, HALO_H = TILE_H + 2;
+    static constexpr int HROW = ((HALO_W * KCP * (int)sizeof(T) + 255) / 256) * 256 / (int)sizeof(T);
+    static constexpr int HALO_ELEMS = HALO_H * HROW;
 };
 
-template <typename T, int BN, int KC> constexpr size_t conv_lds_bytes() {
-    using C = ConvCfg<T, KC>;
+template <typename T, int BN, int KC, int WPG> constexpr size_t conv_lds_bytes() {
+    using C = ConvCfg<T, KC, WPG>;
     size_t main = (size_t)(C::HALO_ELEMS + 9 * BN * C::KCP) * sizeof(T);
-    size_t epi = (size_t)128 * (BN + 4) * sizeof(float);               // output staging, one 128-pixel half at a time
-    size_t st = (size_t)(4 * 2 * BN * 2 + BN * 2) * sizeof(float);     // GroupNorm partials
+    size_t epi = (size_t)(WPG * 32) * (BN + 4) * sizeof(float);          // output staging, half of the tile at a time
+    size_t st = (size_t)(WPG * 2 * BN * 2 + BN * 2) * sizeof(float);     // GroupNorm partials
     size_t m = main > epi ? main : epi;
     return m > st ? m : st;
 }
@@ -54,23 +58,25 @@ template <typename T> struct Params {
     int B, H, W, Cout, groups, up2, tiles_x, tiles_y;
 };
 
-template <typename T, int BN, int KC, bool PF>
-__global__ __launch_bounds__(NTHREADS, CONV_WAVES) void conv3x3_kernel(Params<T> p) {
-    using C = ConvCfg<T, KC>;
-    constexpr int KCP = C::KCP, HROW = C::HROW;
-    constexpr int NR = BN / 32, MR = 2;
+template <typename T, int BN, int KC, bool PF, int WPG, int WNG>
+__global__ __launch_bounds__(64 * WPG * WNG, (WPG * WNG) / 2) void conv3x3_kernel(Params<T> p) {
+    using C = ConvCfg<T, KC, WPG>;
+    constexpr int NTHREADS = 64 * WPG * WNG;
+    constexpr int KCP = C::KCP, HROW = C::HROW, TILE_H = C::TILE_H, HALO_H = C::HALO_H;
+    constexpr int NR = BN / 32 / WNG, MR = 2;
     constexpr int V = KC / 8;  // 8-element vectors per pixel per chunk
-    constexpr int NH = (HALO * HALO * V + NTHREADS - 1) / NTHREADS;  // halo vectors per thread per chunk
+    constexpr int NH = (HALO_H * HALO_W * V + NTHREADS - 1) / NTHREADS;  // halo vectors per thread per chunk
     constexpr int NW = (9 * BN * V + NTHREADS - 1) / NTHREADS;       // weight vectors per thread per chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* halo = reinterpret_cast<T*>(smem_raw);
     T* wl = halo + C::HALO_ELEMS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pg = wave % WPG, ng = wave / WPG;  // pixel group / channel group of this wave
     const int r = lane & 31, hf = lane >> 5;
     const int tiles = p.tiles_x * p.tiles_y;
     const int b = blockIdx.x / tiles, tile = blockIdx.x % tiles;
-    const int ty0 = (tile / p.tiles_x) * TILE, tx0 = (tile % p.tiles_x) * TILE;
+    const int ty0 = (tile / p.tiles_x) * TILE_H, tx0 = (tile % p.tiles_x) * TILE_W;
     const int n0 = blockIdx.y * BN;
     const int Hs = p.up2 ? p.H >> 1 : p.H, Ws = p.up2 ? p.W >> 1 : p.W;  // source dims
     const int nch0 = (p.C[0] + KC - 1) / KC, nch1 = (p.C[1] + KC - 1) / KC, nch = nch0 + nch1;
@@ -102,9 +108,9 @@ __global__ __launch_bounds__(NTHREADS, CONV_WAVES) void conv3x3_kernel(Params<T>
         for (int i = 0; i < NH; i++) {
             const int idx = tid + i * NTHREADS;
             const int pix = idx / V;
-            const int hy = pix / HALO, hx = pix - hy * HALO;
+            const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
             const int Y = ty0 + hy - 1, X = tx0 + hx - 1;
-            const bool ok = (idx < HALO * HALO * V) && chv && Y >= 0 && Y < p.H && X >= 0 && X < p.W;
+            const bool ok = (idx < HALO_H * HALO_W * V) && chv && Y >= 0 && Y < p.H && X >= 0 && X < p.W;
 #ifdef ABL_NO_GLOAD
             if (ok && p.B == 12345) {
 #else
@@ -154,9 +160,9 @@ __global__ __launch_bounds__(NTHREADS, CONV_WAVES) void conv3x3_kernel(Params<T>
 #pragma unroll
         for (int i = 0; i < NH; i++) {
             const int idx = tid + i * NTHREADS;
-            if (idx < HALO * HALO * V) {
+            if (idx < HALO_H * HALO_W * V) {
                 const int pix = idx / V;
-                const int hy = pix / HALO, hx = pix - hy * HALO;
+                const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
                 frag_store<T>(hreg[i], halo + hy * HROW + hx * KCP + c8 * 8);
             }
         }
@@ -184,12 +190,12 @@ __global__ __launch_bounds__(NTHREADS, CONV_WAVES) void conv3x3_kernel(Params<T>
                 Frag<T> fa[MR], fb[NR];
 #pragma unroll
                 for (int mr = 0; mr < MR; mr++) {
-                    const int py = wave * 4 + mr * 2 + (r >> 4), px = r & 15;
+                    const int py = pg * 4 + mr * 2 + (r >> 4), px = r & 15;
                     frag_load<T>(fa[mr], halo + (py + ky) * HROW + (px + kx) * KCP + kk * 16 + hf * 8);
                 }
 #pragma unroll
                 for (int nr = 0; nr < NR; nr++)
-                    frag_load<T>(fb[nr], wl + (tap * BN + nr * 32 + r) * KCP + kk * 16 + hf * 8);
+                    frag_load<T>(fb[nr], wl + (tap * BN + (ng * NR + nr) * 32 + r) * KCP + kk * 16 + hf * 8);
 #pragma unroll
                 for (int mr = 0; mr < MR; mr++)
 #pragma unroll
@@ -222,15 +228,16 @@ __global__ __launch_bounds__(NTHREADS, CONV_WAVES) void conv3x3_kernel(Params<T>
     for (int mr = 0; mr < MR; mr++) {
 #pragma unroll
         for (int nr = 0; nr < NR; nr++) {
-            const int n = n0 + nr * 32 + r;
+            const int nl = (ng * NR + nr) * 32 + r;
+            const int n = n0 + nl;
             const bool nv = n < p.Cout;
             const float bias = nv ? p.bias[n] : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int row = acc_row(e, lane);
-                const int Y = ty0 + wave * 4 + mr * 2 + (row >> 4), X = tx0 + (row & 15);
+                const int Y = ty0 + pg * 4 + mr * 2 + (row >> 4), X = tx0 + (row & 15);
                 const float v = acc[mr][nr][e] + bias;
-                ot[(wave * 32 + row) * OS + nr * 32 + r] = v;
+                ot[(pg * 32 + row) * OS + nl] = v;
                 if (nv && Y < p.H && X < p.W) {
                     cs[nr] += v;
                     css[nr] += v * v;
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(NTHREADS, CONV_WAVES) void conv3x3_kernel(Params<T>
             }
         }
         __syncthreads();
-        for (int idx = tid; idx < 128 * (BN / 8); idx += NTHREADS) {
+        for (int idx = tid; idx < WPG * 32 * (BN / 8); idx += NTHREADS) {
             const int pl = idx / (BN / 8), v8 = idx - pl * (BN / 8);
             const int wv = pl >> 5, row = pl & 31;
             const int Y = ty0 + wv * 4 + mr * 2 + (row >> 4), X = tx0 + (row & 15);
@@ -264,11 +271,11 @@ __global__ __launch_bounds__(NTHREADS, CONV_WAVES) void conv3x3_kernel(Params<T>
         __syncthreads();
     }
     if (p.stats != nullptr) {
-        float* st = reinterpret_cast<float*>(smem_raw);  // [wave][half][BN][2], then [BN][2]
-        float* col = st + 4 * 2 * BN * 2;
+        float* st = reinterpret_cast<float*>(smem_raw);  // [pixel group][half][BN][2], then [BN][2]
+        float* col = st + WPG * 2 * BN * 2;
 #pragma unroll
         for (int nr = 0; nr < NR; nr++) {
-            float* d = st + (((wave * 2 + hf) * BN) + nr * 32 + r) * 2;
+            float* d = st + (((pg * 2 + hf) * BN) + (ng * NR + nr) * 32 + r) * 2;
             d[0] = cs[nr];
             d[1] = css[nr];
         }
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(NTHREADS, CONV_WAVES) void conv3x3_kernel(Params<T>
         if (tid < BN) {
             float s = 0.f, ss = 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {  // fixed order -> deterministic
+            for (int k = 0; k < WPG * 2; k++) {  // fixed order -> deterministic
                 s += st[(k * BN + tid) * 2];
                 ss += st[(k * BN + tid) * 2 + 1];
             }
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(NTHREADS, CONV_WAVES) void conv3x3_kernel(Params<T>
     }
 }
 
-template <typename T, int BN, int KC, bool PF>
+template <typename T, int BN, int KC, bool PF, int WPG, int WNG>
 int launch(const dig_conv3x3_args* a, hipStream_t stream) {
     Params<T> p;
     p.in[0] = (const T*)a->in0;
@@ -316,40 +323,46 @@ int launch(const dig_conv3x3_args* a, hipStream_t stream) {
     p.stats = a->stats;
     p.bstride0 = a->in0_bstride > 0 ? a->in0_bstride : (long long)(a->up2 ? (a->H / 2) * (a->W / 2) : a->H * a->W) * a->C0;
     p.B = a->B; p.H = a->H; p.W = a->W; p.Cout = a->Cout; p.groups = a->groups; p.up2 = a->up2;
-    p.tiles_x = cdiv(a->W, TILE);
-    p.tiles_y = cdiv(a->H, TILE);
-    constexpr size_t lds = conv_lds_bytes<T, BN, KC>();
+    p.tiles_x = cdiv(a->W, TILE_W);
+    p.tiles_y = cdiv(a->H, 4 * WPG);
+    constexpr size_t lds = conv_lds_bytes<T, BN, KC, WPG>();
     static bool attr_set[64] = {};  // per instantiation, per device
     int dev = 0;
     (void)hipGetDevice(&dev);
     dev &= 63;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel<T, BN, KC, PF>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel<T, BN, KC, PF, WPG, WNG>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "conv3x3: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
         attr_set[dev] = true;
     }
     dim3 grid(a->B * p.tiles_x * p.tiles_y, cdiv(a->Cout, BN));
-    hipLaunchKernelGGL((conv3x3_kernel<T, BN, KC, PF>), grid, dim3(NTHREADS), lds, stream, p);
+    hipLaunchKernelGGL((conv3x3_kernel<T, BN, KC, PF, WPG, WNG>), grid, dim3(64 * WPG * WNG), lds, stream, p);
     DIG_LAUNCH_CHECK("conv3x3");
     return DIG_OK;
 }
 
 // tile configuration per (Cout, dtype): the weight packer (host) and the launcher must agree
-void conv_config(int Cout, int dtype, int* BN, int* KC) {
+void conv_config(int Cout, int dtype, int* BN, int* KC, int* TH) {
     int bn = (Cout % 128 == 0) ? 128 : (Cout > 32 ? 64 : 32);
     if (dtype == DIG_F32 && bn > 64) bn = 64;
     *BN = bn;
     *KC = (dtype == DIG_F32) ? 16 : (bn == 32 ? 32 : 16);
+    *TH = (dtype == DIG_BF16 && bn == 64) ? 4 * CONV_WPG64 : 16;  // tile height (width is always 16)
 }
 
 }  // namespace
 
-extern "C" int dig_conv3x3_tiles(int H, int W) { return cdiv(H, TILE) * cdiv(W, TILE); }
+extern "C" int dig_conv3x3_tiles(int H, int W, int Cout, int dtype) {
+    int BN, KC, TH;
+    conv_config(Cout, dtype, &BN, &KC, &TH);
+    return cdiv(H, TH) * cdiv(W, TILE_W);
+}
 
 extern "C" int dig_conv3x3_config(int Cout, int dtype, int* BN, int* KC) {
     DIG_CHECK(Cout > 0 && BN && KC && (dtype == DIG_BF16 || dtype == DIG_F32), DIG_EINVAL, "conv3x3_config: bad argument");
-    conv_config(Cout, dtype, BN, KC);
+    int TH;
+    conv_config(Cout, dtype, BN, KC, &TH);
     return DIG_OK;
 }
 
@@ -363,8 +376,8 @@ extern "C" int dig_conv3x3(const dig_conv3x3_args* a, void* stream_) {
     DIG_CHECK(((uintptr_t)a->in0 | (uintptr_t)a->in1 | (uintptr_t)a->w | (uintptr_t)a->out) % 16 == 0, DIG_EALIGN,
               "conv3x3: pointers must be 16-byte aligned");
     DIG_CHECK(a->dtype == DIG_BF16 || a->dtype == DIG_F32, DIG_EINVAL, "conv3x3: unknown dtype %d", a->dtype);
-    int BN, KC;
-    conv_config(a->Cout, a->dtype, &BN, &KC);
+    int BN, KC, TH;
+    conv_config(a->Cout, a->dtype, &BN, &KC, &TH);
     if (a->stats) {
         DIG_CHECK(a->groups > 0 && a->Cout % a->groups == 0, DIG_EINVAL, "conv3x3: Cout %% groups != 0");
         const int cpg = a->Cout / a->groups;
@@ -372,10 +385,10 @@ extern "C" int dig_conv3x3(const dig_conv3x3_args* a, void* stream_) {
                   "conv3x3: GroupNorm group width %d does not tile the %d-channel block", cpg, BN);
     }
     if (a->dtype == DIG_BF16) {
-        if (BN == 128) return launch<bf16, 128, 16, CONV_PF128>(a, stream);
-        if (BN == 64) return launch<bf16, 64, 16, CONV_PF64>(a, stream);
-        return launch<bf16, 32, 32, true>(a, stream);
+        if (BN == 128) return launch<bf16, 128, 16, CONV_PF128, 4, CONV_WNG128>(a, stream);
+        if (BN == 64) return launch<bf16, 64, 16, CONV_PF64, CONV_WPG64, 1>(a, stream);
+        return launch<bf16, 32, 32, true, 4, 1>(a, stream);
     }
-    if (BN == 64) return launch<float, 64, 16, false>(a, stream);
-    return launch<float, 32, 16, false>(a, stream);
+    if (BN == 64) return launch<float, 64, 16, false, 4, 1>(a, stream);
+    return launch<float, 32, 16, false, 4, 1>(a, stream);
 }

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for fn in declared:
         assert hasattr(L, fn), fn
     assert L.dig_version() >= 100
-    assert L.dig_conv3x3_tiles(256, 256) == 256 and L.dig_conv3x3_tiles(28, 28) == 4
+    assert L.dig_conv3x3_tiles(256, 256, 512, 0) == 256 and L.dig_conv3x3_tiles(28, 28, 512, 1) == 4
 
 
 def test_struct_mirror_sizes():
