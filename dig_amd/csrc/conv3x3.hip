@@ -28,6 +28,9 @@ constexpr int HALO_W = TILE_W + 2;  // 18
 #ifndef CONV_WPG64
 #define CONV_WPG64 4
 #endif
+#ifndef CONV_KC64
+#define CONV_KC64 16
+#endif
 
 // WPG = waves along pixels (each owns 4 tile rows = 64 pixels), WNG = waves along output channels
 template <typename T, int KC, int WPG> struct ConvCfg {
@@ -347,7 +350,7 @@ void conv_config(int Cout, int dtype, int* BN, int* KC, int* TH) {
     int bn = (Cout % 128 == 0) ? 128 : (Cout > 32 ? 64 : 32);
     if (dtype == DIG_F32 && bn > 64) bn = 64;
     *BN = bn;
-    *KC = (dtype == DIG_F32) ? 16 : (bn == 32 ? 32 : 16);
+    *KC = (dtype == DIG_F32) ? 16 : (bn == 32 ? 32 : (bn == 64 ? CONV_KC64 : 16));
     *TH = (dtype == DIG_BF16 && bn == 64) ? 4 * CONV_WPG64 : 16;  // tile height (width is always 16)
 }
 
@@ -386,7 +389,7 @@ extern "C" int dig_conv3x3(const dig_conv3x3_args* a, void* stream_) {
     }
     if (a->dtype == DIG_BF16) {
         if (BN == 128) return launch<bf16, 128, 16, CONV_PF128, 4, CONV_WNG128>(a, stream);
-        if (BN == 64) return launch<bf16, 64, 16, CONV_PF64, CONV_WPG64, 1>(a, stream);
+        if (BN == 64) return launch<bf16, 64, CONV_KC64, CONV_PF64, CONV_WPG64, 1>(a, stream);
         return launch<bf16, 32, 32, true, 4, 1>(a, stream);
     }
     if (BN == 64) return launch<float, 64, 16, false, 4, 1>(a, stream);

@@ -244,6 +244,8 @@ def _pack_unet(u, dt):
             d["wo"], d["bo"] = _conv1_pack(m.to_out, dt)
         else:
             d["wq"], d["wkv"] = wqkv[:hid].contiguous(), wqkv[hid:].contiguous()
+            wg = (m.to_qkv.weight.detach().float().reshape(3 * hid, -1) * m.norm.g.detach().float().reshape(1, -1))
+            d["wq_g"], d["wkv_g"] = wg[:hid].contiguous().to(dt), wg[hid:].contiguous().to(dt)  # RMSNorm gain folded in
             d["wo"], d["bo"] = _conv1_pack(m.to_out[0], dt)
             d["g2"] = f32(m.to_out[1].g.reshape(-1))
         return d
@@ -300,8 +302,9 @@ def _resnet(p, x0, x1, ss_all, debug=None):
     return ops.linear_rows(x0, wr, bias=br, x1=x1, gsrc=c2, gaff=aff2, rows_per_img=hw)
 
 
-def _linear_attention(p, x):
-    """LinearAttention (ddp.py:196-233) + the caller's residual (ddp.py:402,430)."""
+def _linear_attention_unfused(p, x):
+    """LinearAttention (ddp.py:196-233) + the caller's residual, as separate GEMM / softmax / context kernels
+    (used when the fused kernels' shape constraints do not hold)."""
     B, H, W, C = x.shape
     n, heads = H * W, p["heads"]
     hid = heads * 32
@@ -333,6 +336,32 @@ def _linear_attention(p, x):
     y = torch.empty(B, H, W, dim, dtype=dt, device=x.device)
     ops.gemm_nt(q, Mb, y, n, dim, hid, dtype=dt, bias=p["bo"], batch=B, sa=(n * hid, 0), sb=(dim * hid, 0), sc=(n * dim, 0))
     return ops.rmsnorm(y, p["g2"], res=x)
+
+
+def _linear_attention(p, x):
+    """LinearAttention (ddp.py:196-233) + the caller's residual (ddp.py:402,430), fused: pass A (k, v, online softmax,
+    context) -> merge + M_b -> pass B (q, softmax, M_b q, RMSNorm, residual).  x is read twice, the result written once."""
+    B, H, W, C = x.shape
+    n, heads = H * W, p["heads"]
+    dim = p["wo"].shape[0]
+    if heads != 4 or n % 32 != 0 or C not in (16, 32, 64, 128, 256) or dim != C:
+        return _linear_attention_unfused(p, x)
+    dt = x.dtype
+    dc = dtype_code(dt)
+    tiles = (n + 63) // 64
+    splits = max(1, min(64, tiles // 4, max(1, 2048 // B)))
+    part = torch.empty(B, splits, 4, 32, 32, dtype=torch.float32, device=x.device)
+    pmax = torch.empty(B, splits, 4, 32, dtype=torch.float32, device=x.device)
+    psum = torch.empty(B, splits, 4, 32, dtype=torch.float32, device=x.device)
+    call("la_kvctx", x=x, wkv=p["wkv_g"], part=part, pmax=pmax, psum=psum, B=B, n=n, C=C, hid=128, splits=splits, dtype=dc)
+    ctx = torch.empty(B * 4, 32, 32, dtype=dt, device=x.device)  # [bh][d][e]
+    call("la_merge", part=part, pmax=pmax, psum=psum, ctx=ctx, B=B, splits=splits, dtype=dc)
+    Mb = torch.empty(B, dim, 128, dtype=dt, device=x.device)
+    ops.gemm_nt(p["wo"], ctx, Mb, dim, 32, 32, dtype=dt, lda0=128, ldb=32, ldc=128, batch=B * 4, z_inner=4,
+                sa=(0, 32), sb=(4 * 1024, 1024), sc=(dim * 128, 32))
+    out = torch.empty_like(x)
+    call("la_out", x=x, wq=p["wq_g"], mb=Mb, bias=p["bo"], g2=p["g2"], out=out, B=B, n=n, C=C, dim=dim, dtype=dc, scale=32 ** -0.5)
+    return out
 
 
 def _full_attention(p, x):

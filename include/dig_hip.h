@@ -174,6 +174,42 @@ typedef struct {
 } dig_la_finalize_args;
 int dig_la_finalize(const dig_la_finalize_args* a, void* stream);
 
+/* ---- fused LinearAttention (ddp.py:196-233): x is read twice and the result written once ------------------------
+ *   dig_la_kvctx: per (image, pixel split), one wave per head: k,v = W'kv x with RMSNorm folded (g into the weights,
+ *                 1/||x|| as a row scale), online softmax of k over pixels, ctxT[e][d] += v^T exp(k - m) with both MFMA
+ *                 operands taken from the accumulators.  wkv: [256][C] = (k rows | v rows) * g.  Outputs per
+ *                 (b, split, head): part [32 e][32 d] fp32, pmax[32 d], psum[32 d].  Needs 4 heads of 32, C in {16..256}.
+ *   dig_la_merge: log-sum-exp merge of the splits -> ctx[b][h][d][e] in dtype (B operand of the M_b GEMM).
+ *   dig_la_out  : q = softmax_d(W'q x) * scale, y = M_b q + bias, out = RMSNorm(y) * g2 + x.   mb: [B][dim][128]. */
+typedef struct {
+    const void* x;
+    const void* wkv;
+    float* part;
+    float* pmax;
+    float* psum;
+    int B, n, C, hid, splits, dtype;
+} dig_la_kvctx_args;
+int dig_la_kvctx(const dig_la_kvctx_args* a, void* stream);
+typedef struct {
+    const float* part;
+    const float* pmax;
+    const float* psum;
+    void* ctx;
+    int B, splits, dtype;
+} dig_la_merge_args;
+int dig_la_merge(const dig_la_merge_args* a, void* stream);
+typedef struct {
+    const void* x;
+    const void* wq;
+    const void* mb;
+    const float* bias;
+    const float* g2;
+    void* out;
+    int B, n, C, dim, dtype;
+    float scale;
+} dig_la_out_args;
+int dig_la_out(const dig_la_out_args* a, void* stream);
+
 /* ---- stem: normalisation + q_sample + conv7x7 -------------------------------------------------------
  * Replaces denormforDiff/normalize (model.py:499-508, ddp.py:82-83), extract + q_sample (ddp.py:452-455,
  * 853-860) and init_conv (ddp.py:296,388).  img, noise: NCHW fp32 [B][3][H][W];

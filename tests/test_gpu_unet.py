@@ -89,12 +89,15 @@ def test_blocks_vs_golden_ops(golden, dt, tl):
             d["wo"], d["bo"] = _conv1_pack(m.to_out, dt)
         else:
             d["wq"], d["wkv"] = wqkv[:hid].contiguous(), wqkv[hid:].contiguous()
+            wg = (m.to_qkv.weight.detach().float().reshape(3 * hid, -1) * m.norm.g.detach().float().reshape(1, -1))
+            d["wq_g"], d["wkv_g"] = wg[:hid].contiguous().to(dt), wg[hid:].contiguous().to(dt)
             d["wo"], d["bo"] = _conv1_pack(m.to_out[0], dt)
             d["g2"] = m.to_out[1].g.reshape(-1).float().contiguous()
         return d
-    y = D._linear_attention(pack_attn(la), xd)
     ref = T(g["linattn"]) + x
-    assert (nchw(y) - ref).abs().max() <= tl * max(1, ref.abs().max())
+    for fn in (D._linear_attention, D._linear_attention_unfused):
+        y = fn(pack_attn(la), xd)
+        assert (nchw(y) - ref).abs().max() <= tl * max(1, ref.abs().max()), fn.__name__
     y = D._full_attention(pack_attn(fa), xd)
     ref = T(g["fullattn"]) + x
     assert (nchw(y) - ref).abs().max() <= tl * max(1, ref.abs().max())
