@@ -35,14 +35,100 @@ template <> __device__ __forceinline__ void load_4_4<float>(Frag<float>& f, cons
     f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
 }
 
+template <typename T> __device__ __forceinline__ void load4f(float (&o)[4], const T* p);
+template <> __device__ __forceinline__ void load4f<bf16>(float (&o)[4], const bf16* p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
+}
+template <> __device__ __forceinline__ void load4f<float>(float (&o)[4], const float* p) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+}
+template <typename T> __device__ __forceinline__ void store4f(T* p, const float (&o)[4]);
+template <> __device__ __forceinline__ void store4f<bf16>(bf16* p, const float (&o)[4]) {
+    *reinterpret_cast<bf16x4*>(p) = bf16x4{(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+}
+template <> __device__ __forceinline__ void store4f<float>(float* p, const float (&o)[4]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{o[0], o[1], o[2], o[3]};
+}
+template <typename T> __device__ __forceinline__ void copy4(T* d, const T* s);
+template <> __device__ __forceinline__ void copy4<bf16>(bf16* d, const bf16* s) { *reinterpret_cast<bf16x4*>(d) = *reinterpret_cast<const bf16x4*>(s); }
+template <> __device__ __forceinline__ void copy4<float>(float* d, const float* s) { *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(s); }
+
+constexpr float LOG2E = 1.4426950408889634f;
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32; x <= 0 here
+
 // ------------------------------------------------------------------------------------------------------------
-// pass A
+// pass A.  The pixel tile is RMS-normalised once while it is staged into LDS (F.normalize(x, dim=1) * sqrt(C);
+// g is folded into the weights), so k and v leave the MFMA ready to use; the next tile's rows are prefetched into
+// registers under the current tile's MFMAs.  The online-softmax rescale happens once per 64-pixel tile.
+template <typename T, int KS, bool WREG, bool MASK>
+__device__ __forceinline__ void kv_tile(const T* xs, const Frag<T>* fk, const Frag<T>* fv, const T* wk, const T* wv, f32x16& ctx,
+                                        float& m_run, float& ksum, int valid_rows, int lane) {
+    constexpr int C = KS * 16, CP = C + 8;
+    const int r = lane & 31, hf = lane >> 5;
+    f32x16 ak[2], av[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) ak[sub][e] = av[sub][e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            Frag<T> fa;
+            frag_load<T>(fa, xs + (sub * 32 + r) * CP + ks * 16 + hf * 8);
+            if constexpr (WREG) {
+                mma16<T>(ak[sub], fa, fk[ks]);
+                mma16<T>(av[sub], fa, fv[ks]);
+            } else {
+                Frag<T> gk, gv;
+                frag_load<T>(gk, wk + ks * 16 + hf * 8);
+                frag_load<T>(gv, wv + ks * 16 + hf * 8);
+                mma16<T>(ak[sub], fa, gk);
+                mma16<T>(av[sub], fa, gv);
+            }
+        }
+    }
+    if constexpr (MASK) {  // rows past the end of the image: k = -inf (v is already 0 there: the staged rows are zero)
+#pragma unroll
+        for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                if (sub * 32 + acc_row(e, lane) >= valid_rows) ak[sub][e] = -INFINITY;
+    }
+    float mt = fmaxf(ak[0][0], ak[1][0]);
+#pragma unroll
+    for (int e = 1; e < 16; e++) mt = fmaxf(mt, fmaxf(ak[0][e], ak[1][e]));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float f = exp2_fast((m_run - m_new) * LOG2E);  // 0 on the first tile (m_run = -inf)
+#pragma unroll
+    for (int e = 0; e < 16; e++) ctx[e] *= f;
+    ksum *= f;
+    m_run = m_new;
+    const float mc = m_new * LOG2E;
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            Frag<T> fA, fB;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float pe = exp2_fast(fmaf(ak[sub][8 * s + j], LOG2E, -mc));  // exp2(-inf) = 0 for masked rows
+                ksum += pe;
+                frag_set<T>(fB, j, pe);
+                frag_set<T>(fA, j, av[sub][8 * s + j]);
+            }
+            mma16<T>(ctx, fA, fB);  // ctxT[e][d] += sum_p v[p][e] * kexp[p][d]
+        }
+}
+
 template <typename T, int KS, bool WREG>
-__global__ __launch_bounds__(256) void la_kv_ctx_kernel(dig_la_kvctx_args a) {
+__global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void la_kv_ctx_kernel(dig_la_kvctx_args a) {
     constexpr int C = KS * 16, CP = C + 8, TP = 64;
+    constexpr int LPR = C / 8;                       // lanes that share one pixel row while staging
+    constexpr int NV = (TP * LPR + 255) / 256;       // 16-byte vectors per thread per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T* xs = reinterpret_cast<T*>(smem);                       // [TP][CP]
-    float* winv = reinterpret_cast<float*>(xs + TP * CP);     // [4 waves][32]
+    T* xs = reinterpret_cast<T*>(smem);  // [TP][CP], rows already normalised
     const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, r = lane & 31, hf = lane >> 5;
     const int split = blockIdx.x, b = blockIdx.y;
     const T* x = (const T*)a.x + (size_t)b * a.n * C;
@@ -63,77 +149,42 @@ __global__ __launch_bounds__(256) void la_kv_ctx_kernel(dig_la_kvctx_args a) {
     for (int e = 0; e < 16; e++) ctx[e] = 0.f;
     float m_run = -INFINITY, ksum = 0.f;
     const float sqrtC = sqrtf((float)C);
+    Frag<T> pre[NV];
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int idx = tid + i * 256, row = idx / LPR, v = idx - row * LPR;
+            if (idx < TP * LPR && t * TP + row < a.n) frag_load<T>(pre[i], x + (size_t)(t * TP + row) * C + v * 8);
+            else frag_zero<T>(pre[i]);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int idx = tid + i * 256, row = idx / LPR, v = idx - row * LPR;
+            float xv[8], ssq = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                xv[j] = frag_get<T>(pre[i], j);
+                ssq += xv[j] * xv[j];
+            }
+#pragma unroll
+            for (int o = 1; o < LPR; o <<= 1) ssq += __shfl_xor(ssq, o, 64);  // the LPR lanes of a row are adjacent
+            const float inv = sqrtC / fmaxf(sqrtf(ssq), 1e-12f);              // F.normalize eps (ddp.py:150)
+#pragma unroll
+            for (int j = 0; j < 8; j++) frag_set<T>(pre[i], j, xv[j] * inv);
+            if (idx < TP * LPR) frag_store<T>(pre[i], xs + row * CP + v * 8);
+        }
+    };
+    if (t_begin < t_end) gload(t_begin);
     for (int t = t_begin; t < t_end; t++) {
-        const int p0 = t * TP;
+        __syncthreads();  // previous tile's MFMA reads are done
+        lstore();
         __syncthreads();
-        for (int i = tid; i < TP * (C / 8); i += 256) {
-            const int row = i / (C / 8), v = i - row * (C / 8);
-            Frag<T> f;
-            if (p0 + row < a.n) frag_load<T>(f, x + (size_t)(p0 + row) * C + v * 8);
-            else frag_zero<T>(f);
-            frag_store<T>(f, xs + row * CP + v * 8);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int sub = 0; sub < TP / 32; sub++) {
-            f32x16 ak, av;
-#pragma unroll
-            for (int e = 0; e < 16; e++) ak[e] = av[e] = 0.f;
-            float ssq = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < KS; ks++) {
-                Frag<T> fa;
-                frag_load<T>(fa, xs + (sub * 32 + r) * CP + ks * 16 + hf * 8);
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const float xv = frag_get<T>(fa, j);
-                    ssq += xv * xv;
-                }
-                if constexpr (WREG) {
-                    mma16<T>(ak, fa, fk[ks]);
-                    mma16<T>(av, fa, fv[ks]);
-                } else {
-                    Frag<T> gk, gv;
-                    frag_load<T>(gk, wk + ks * 16 + hf * 8);
-                    frag_load<T>(gv, wv + ks * 16 + hf * 8);
-                    mma16<T>(ak, fa, gk);
-                    mma16<T>(av, fa, gv);
-                }
-            }
-            ssq += __shfl_xor(ssq, 32, 64);
-            if (hf == 0) winv[h * 32 + r] = sqrtC / fmaxf(sqrtf(ssq), 1e-12f);  // RMSNorm row scale of pixel r
-            __builtin_amdgcn_wave_barrier();
-            float mt = -INFINITY;
-            float kv[16];
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int row = acc_row(e, lane);
-                const float inv = winv[h * 32 + row];
-                const bool ok = p0 + sub * 32 + row < a.n;
-                kv[e] = ok ? ak[e] * inv : -INFINITY;
-                av[e] = ok ? av[e] * inv : 0.f;
-                mt = fmaxf(mt, kv[e]);
-            }
-            __builtin_amdgcn_wave_barrier();
-            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-            const float m_new = fmaxf(m_run, mt);
-            const float f = __expf(m_run - m_new);  // 0 on the first tile (m_run = -inf)
-#pragma unroll
-            for (int e = 0; e < 16; e++) ctx[e] *= f;
-            ksum *= f;
-            m_run = m_new;
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                Frag<T> fA, fB;
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    frag_set<T>(fB, j, __expf(kv[8 * s + j] - m_new));  // exp(-inf) = 0 for masked rows
-                    ksum += frag_get<T>(fB, j);                         // what the MFMA sees (rounded to T)
-                    frag_set<T>(fA, j, av[8 * s + j]);
-                }
-                mma16<T>(ctx, fA, fB);  // ctxT[e][d] += sum_p v[p][e] * kexp[p][d]
-            }
-        }
+        if (t + 1 < t_end) gload(t + 1);
+        const int valid = a.n - t * TP;
+        if (valid >= TP) kv_tile<T, KS, WREG, false>(xs, fk, fv, wk, wv, ctx, m_run, ksum, valid, lane);
+        else kv_tile<T, KS, WREG, true>(xs, fk, fv, wk, wv, ctx, m_run, ksum, valid, lane);
     }
     ksum += __shfl_xor(ksum, 32, 64);
     const size_t slot = ((size_t)b * a.splits + split) * 4 + h;
@@ -146,170 +197,216 @@ __global__ __launch_bounds__(256) void la_kv_ctx_kernel(dig_la_kvctx_args a) {
 }
 
 // merge of the splits: ctx[b][h][d][e] = sum_s w_s part_s[e][d] / sum_s w_s ksum_s[d],  w_s = exp(m_s - max_s m_s)
-template <typename T> __global__ void la_merge_kernel(dig_la_merge_args a) {
+template <typename T> __global__ __launch_bounds__(256) void la_merge_kernel(dig_la_merge_args a) {
     const int bh = blockIdx.x, b = bh / 4, h = bh % 4;
     T* out = (T*)a.ctx + (size_t)bh * 1024;
-    for (int i = threadIdx.x; i < 1024; i += blockDim.x) {
-        const int e = i >> 5, d = i & 31;
-        float M = -INFINITY;
-        for (int s = 0; s < a.splits; s++) M = fmaxf(M, a.pmax[(((size_t)b * a.splits + s) * 4 + h) * 32 + d]);
-        float num = 0.f, den = 0.f;
-        for (int s = 0; s < a.splits; s++) {
-            const size_t slot = ((size_t)b * a.splits + s) * 4 + h;
-            const float w = __expf(a.pmax[slot * 32 + d] - M);
-            num += w * a.part[slot * 1024 + i];
-            den += w * a.psum[slot * 32 + d];
-        }
-        out[d * 32 + e] = from_f32<T>(num / den);
+    const int i = blockIdx.y * 256 + threadIdx.x;
+    const int e = i >> 5, d = i & 31;
+    float M = -INFINITY;
+    for (int s = 0; s < a.splits; s++) M = fmaxf(M, a.pmax[(((size_t)b * a.splits + s) * 4 + h) * 32 + d]);
+    float num = 0.f, den = 0.f;
+    for (int s = 0; s < a.splits; s++) {
+        const size_t slot = ((size_t)b * a.splits + s) * 4 + h;
+        const float w = __expf(a.pmax[slot * 32 + d] - M);
+        num += w * a.part[slot * 1024 + i];
+        den += w * a.psum[slot * 32 + d];
     }
+    out[d * 32 + e] = from_f32<T>(num / den);
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// pass B
-template <typename T, int KS, int DT>
-__global__ __launch_bounds__(256) void la_out_kernel(dig_la_out_args a) {
-    constexpr int C = KS * 16, CP = C + 8, TP = 128;
+// pass B.  One wave owns 32 pixels at a time (its own 32 rows of the LDS tile - no block barriers in the loop) and
+// walks `iters` such sub-tiles of one image.  For C <= 64 (WLDS) the q weights and this image's M_b sit in LDS for
+// the block's lifetime, M_b with the columns of every 16-group permuted so that an accumulator-ordered k-fragment
+// is one 16-byte read.
+template <typename T, int KS, int DT, bool WLDS>
+__global__ __launch_bounds__(256, (KS <= 8 ? 2 : 1)) void la_out_kernel(dig_la_out_args a, int iters) {
+    constexpr int C = KS * 16, CP = C + 8, MP = 128 + 8, TP = 128;
+    constexpr int QV = C >= 32 ? 4 : C / 8;  // valid 8-row groups of an output tile (C = 16: 2; otherwise C % 32 == 0)
+    constexpr bool PFX = KS <= 4;  // prefetch the next sub-tile's rows into registers
+    constexpr int NV = (32 * (C / 8) + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T* xs = reinterpret_cast<T*>(smem);  // [TP][CP]
+    T* xs = reinterpret_cast<T*>(smem);                       // [TP][CP]
+    float* bg = reinterpret_cast<float*>(xs + TP * CP);       // bias[DT*32] | g2[DT*32]
+    T* wqs = reinterpret_cast<T*>(bg + 2 * DT * 32);          // [128][CP]            (WLDS)
+    T* mbs = wqs + 128 * CP;                                  // [DT*32][MP] permuted (WLDS)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
-    const long long P = (long long)a.B * a.n;
-    const long long p0 = (long long)blockIdx.x * TP;
-    const T* x = (const T*)a.x;
-    for (int i = tid; i < TP * (C / 8); i += 256) {
-        const int row = i / (C / 8), v = i - row * (C / 8);
-        Frag<T> f;
-        if (p0 + row < P) frag_load<T>(f, x + (size_t)(p0 + row) * C + v * 8);
-        else frag_zero<T>(f);
-        frag_store<T>(f, xs + row * CP + v * 8);
+    const int b = blockIdx.y;
+    const T* x = (const T*)a.x + (size_t)b * a.n * C;
+    T* out = (T*)a.out + (size_t)b * a.n * C;
+    const T* Mb = (const T*)a.mb + (size_t)b * a.dim * 128;
+    for (int i = tid; i < DT * 32; i += 256) {
+        bg[i] = i < C ? a.bias[i] : 0.f;
+        bg[DT * 32 + i] = i < C ? a.g2[i] : 0.f;
+    }
+    if constexpr (WLDS) {
+        for (int i = tid; i < 128 * (C / 8); i += 256) {
+            const int row = i / (C / 8), v = i - row * (C / 8);
+            Frag<T> f;
+            frag_load<T>(f, (const T*)a.wq + (size_t)row * C + v * 8);
+            frag_store<T>(f, wqs + row * CP + v * 8);
+        }
+        for (int i = tid; i < DT * 32 * 32; i += 256) {
+            const int row = i >> 5, pc = i & 31, g = pc >> 2, q = pc & 3;
+            const int nq = (q == 1) ? 2 : (q == 2) ? 1 : q;  // [0-3 | 8-11 | 4-7 | 12-15]: lane half hf reads 8 contiguous
+            if (row < C) copy4<T>(mbs + row * MP + g * 16 + nq * 4, Mb + (size_t)row * 128 + pc * 4);
+            else {
+                const float z[4] = {0.f, 0.f, 0.f, 0.f};
+                store4f<T>(mbs + row * MP + g * 16 + nq * 4, z);
+            }
+        }
     }
     __syncthreads();
-    const long long pw = p0 + wave * 32;  // first pixel of this wave's sub-tile (n % 32 == 0: one image per sub-tile)
-    if (pw >= P) return;
-    const int b = (int)(pw / a.n);
     T* xw = xs + wave * 32 * CP;
-    // ---- q[n'][p] = Wq'[n'] . x[p]: head h = M tile h, pixel = column (lane)
-    f32x16 aq[4];
+    const int nsub = a.n / 32;
+    const int sub0 = blockIdx.x * iters * 4 + wave;  // this wave's sub-tiles: sub0, sub0 + 4, ...
+    Frag<T> pre[NV];
+    auto gload = [&](int sub) {
 #pragma unroll
-    for (int hh = 0; hh < 4; hh++)
-#pragma unroll
-        for (int e = 0; e < 16; e++) aq[hh][e] = 0.f;
-    float ssq = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ks++) {
-        Frag<T> fb;
-        frag_load<T>(fb, xw + r * CP + ks * 16 + hf * 8);
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const float xv = frag_get<T>(fb, j);
-            ssq += xv * xv;
+        for (int i = 0; i < NV; i++) {
+            const int idx = lane + i * 64, row = idx / (C / 8), v = idx - row * (C / 8);
+            if (idx < 32 * (C / 8)) frag_load<T>(pre[i], x + ((size_t)sub * 32 + row) * C + v * 8);
         }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int idx = lane + i * 64, row = idx / (C / 8), v = idx - row * (C / 8);
+            if (idx < 32 * (C / 8)) frag_store<T>(pre[i], xw + row * CP + v * 8);
+        }
+    };
+    if (PFX && sub0 < nsub) gload(sub0);
+    for (int it = 0; it < iters; it++) {
+        const int sub = sub0 + it * 4;
+        if (sub >= nsub) break;
+        if (!PFX) gload(sub);
+        __builtin_amdgcn_wave_barrier();
+        lstore();
+        __builtin_amdgcn_wave_barrier();
+        if (PFX && it + 1 < iters && sub + 4 < nsub) gload(sub + 4);
+        // ---- q[n'][p] = Wq'[n'] . x[p] per head (M tile = head, pixel = column), softmax over d, * scale -> B fragments
+        Frag<T> qf[4][2];
+        float c2 = 0.f;
 #pragma unroll
         for (int hh = 0; hh < 4; hh++) {
-            Frag<T> fa;
-            frag_load<T>(fa, (const T*)a.wq + (size_t)(hh * 32 + r) * C + ks * 16 + hf * 8);
-            mma16<T>(aq[hh], fa, fb);
-        }
-    }
-    ssq += __shfl_xor(ssq, 32, 64);
-    const float inv = sqrtf((float)C) / fmaxf(sqrtf(ssq), 1e-12f);
-    // ---- softmax over d (the 32 rows of each head tile: 16 registers x 2 lane halves), * scale; keep as B fragments
-    Frag<T> qf[4][2];
+            f32x16 aq;
 #pragma unroll
-    for (int hh = 0; hh < 4; hh++) {
-        float mx = -INFINITY;
+            for (int e = 0; e < 16; e++) aq[e] = 0.f;
+            float ssq = 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            aq[hh][e] *= inv;
-            mx = fmaxf(mx, aq[hh][e]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sm = 0.f;
+            for (int ks = 0; ks < KS; ks++) {
+                Frag<T> fb, fa;
+                frag_load<T>(fb, xw + r * CP + ks * 16 + hf * 8);
+                if (hh == 0) {
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            aq[hh][e] = __expf(aq[hh][e] - mx);
-            sm += aq[hh][e];
-        }
-        sm += __shfl_xor(sm, 32, 64);
-        const float sc = a.scale / sm;
-#pragma unroll
-        for (int s = 0; s < 2; s++)
-#pragma unroll
-            for (int j = 0; j < 8; j++) frag_set<T>(qf[hh][s], j, aq[hh][8 * s + j] * sc);
-    }
-    // ---- y[c][p] = sum_n' Mb[c][n'] qs[n'][p]  (+ bias), contraction over the accumulator rows of q
-    const T* Mb = (const T*)a.mb + (size_t)b * a.dim * 128;
-    f32x16 ay[DT];
-    float ss2 = 0.f;
-#pragma unroll
-    for (int ct = 0; ct < DT; ct++) {
-#pragma unroll
-        for (int e = 0; e < 16; e++) ay[ct][e] = 0.f;
-        const int c = ct * 32 + r;
-        const bool cv = c < a.dim;
-#pragma unroll
-        for (int hh = 0; hh < 4; hh++)
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                Frag<T> fa;
-                if (cv) {
-                    const T* mp = Mb + (size_t)c * 128 + hh * 32 + 16 * s + 4 * hf;  // elements j<4 at +0..3, j>=4 at +8..11 (acc_k)
-                    load_4_4<T>(fa, mp, mp + 8);
-                } else {
-                    frag_zero<T>(fa);
+                    for (int j = 0; j < 8; j++) {
+                        const float xv = frag_get<T>(fb, j);
+                        ssq += xv * xv;
+                    }
                 }
-                mma16<T>(ay[ct], fa, qf[hh][s]);
+                if constexpr (WLDS) frag_load<T>(fa, wqs + (hh * 32 + r) * CP + ks * 16 + hf * 8);
+                else frag_load<T>(fa, (const T*)a.wq + (size_t)(hh * 32 + r) * C + ks * 16 + hf * 8);
+                mma16<T>(aq, fa, fb);
+            }
+            if (hh == 0) {
+                ssq += __shfl_xor(ssq, 32, 64);
+                c2 = LOG2E * sqrtf((float)C) / fmaxf(sqrtf(ssq), 1e-12f);  // RMSNorm scale of this pixel (g is in Wq'), in log2 units
+            }
+            float mx = aq[0];
+#pragma unroll
+            for (int e = 1; e < 16; e++) mx = fmaxf(mx, aq[e]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mc = mx * c2;
+            float sm = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                aq[e] = exp2_fast(fmaf(aq[e], c2, -mc));
+                sm += aq[e];
+            }
+            sm += __shfl_xor(sm, 32, 64);
+            const float sc = a.scale / sm;
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) frag_set<T>(qf[hh][s], j, aq[8 * s + j] * sc);
+        }
+        // ---- y[c][p] = bias[c] + sum_n' Mb[c][n'] qs[n'][p]: contraction over the accumulator rows of q
+        f32x16 ay[DT];
+        float ss2 = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < DT; ct++) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bg + ct * 32 + 8 * q4 + 4 * hf);
+#pragma unroll
+                for (int j = 0; j < 4; j++) ay[ct][4 * q4 + j] = bv[j];
             }
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const int cc = ct * 32 + acc_row(e, lane);
-            const float v = cc < a.dim ? ay[ct][e] + a.bias[cc] : 0.f;
-            ay[ct][e] = v;
-            ss2 += v * v;
+            for (int hh = 0; hh < 4; hh++)
+#pragma unroll
+                for (int s = 0; s < 2; s++) {
+                    Frag<T> fa;
+                    if constexpr (WLDS) {
+                        frag_load<T>(fa, mbs + (ct * 32 + r) * MP + hh * 32 + 16 * s + 8 * hf);
+                    } else {
+                        const T* mp = Mb + (size_t)(ct * 32 + r) * 128 + hh * 32 + 16 * s + 4 * hf;  // j<4 at +0..3, j>=4 at +8..11 (acc_k)
+                        load_4_4<T>(fa, mp, mp + 8);
+                    }
+                    mma16<T>(ay[ct], fa, qf[hh][s]);
+                }
+#pragma unroll
+            for (int e = 0; e < 4 * QV; e++) ss2 += ay[ct][e] * ay[ct][e];
         }
-    }
-    ss2 += __shfl_xor(ss2, 32, 64);
-    const float sc2 = sqrtf((float)a.dim) / fmaxf(sqrtf(ss2), 1e-12f);
-    // ---- RMSNorm * g2 + residual, written into this wave's own rows of the LDS tile (dim == C for LinearAttention)
+        ss2 += __shfl_xor(ss2, 32, 64);
+        const float sc2 = sqrtf((float)a.dim) / fmaxf(sqrtf(ss2), 1e-12f);
+        // ---- RMSNorm * g2 + residual, in place in this wave's own rows of the LDS tile (dim == C)
 #pragma unroll
-    for (int ct = 0; ct < DT; ct++)
+        for (int ct = 0; ct < DT; ct++) {
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const int cc = ct * 32 + acc_row(e, lane);
-            if (cc < a.dim) {
-                T* px = xw + r * CP + cc;
-                *px = from_f32<T>(ay[ct][e] * sc2 * a.g2[cc] + to_f32<T>(*px));
+            for (int q4 = 0; q4 < QV; q4++) {
+                const int c0 = ct * 32 + 8 * q4 + 4 * hf;
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(bg + DT * 32 + c0);
+                float xv[4];
+                load4f<T>(xv, xw + r * CP + c0);
+#pragma unroll
+                for (int j = 0; j < 4; j++) xv[j] = fmaf(ay[ct][4 * q4 + j] * sc2, gv[j], xv[j]);
+                store4f<T>(xw + r * CP + c0, xv);
             }
         }
-    __builtin_amdgcn_wave_barrier();
-    T* out = (T*)a.out;
-    for (int i = lane; i < 32 * (C / 8); i += 64) {
-        const int row = i / (C / 8), v = i - row * (C / 8);
-        if (pw + row < P) {
-            Frag<T> f;
-            frag_load<T>(f, xw + row * CP + v * 8);
-            frag_store<T>(f, out + (size_t)(pw + row) * C + v * 8);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int idx = lane + i * 64, row = idx / (C / 8), v = idx - row * (C / 8);
+            if (idx < 32 * (C / 8)) {
+                Frag<T> f;
+                frag_load<T>(f, xw + row * CP + v * 8);
+                frag_store<T>(f, out + ((size_t)sub * 32 + row) * C + v * 8);
+            }
         }
     }
 }
 
 template <typename T, int KS> int launch_kvctx(const dig_la_kvctx_args* a, hipStream_t st) {
     constexpr int C = KS * 16;
-    const size_t lds = (size_t)64 * (C + 8) * sizeof(T) + 4 * 32 * sizeof(float);
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)la_kv_ctx_kernel<T, KS, (KS <= 8)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((la_kv_ctx_kernel<T, KS, (KS <= 8)>), dim3(a->splits, a->B), dim3(256), lds, st, *a);
+    const size_t lds = (size_t)64 * (C + 8) * sizeof(T);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)la_kv_ctx_kernel<T, KS, (KS <= 4)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((la_kv_ctx_kernel<T, KS, (KS <= 4)>), dim3(a->splits, a->B), dim3(256), lds, st, *a);
     return 0;
 }
 template <typename T, int KS> int launch_out(const dig_la_out_args* a, hipStream_t st) {
     constexpr int C = KS * 16, DT = (C + 31) / 32;
-    const size_t lds = (size_t)128 * (C + 8) * sizeof(T);
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)la_out_kernel<T, KS, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const long long P = (long long)a->B * a->n;
-    hipLaunchKernelGGL((la_out_kernel<T, KS, DT>), dim3((unsigned)((P + 127) / 128)), dim3(256), lds, st, *a);
+    constexpr bool WLDS = KS <= 4;
+    size_t lds = (size_t)128 * (C + 8) * sizeof(T) + 2 * DT * 32 * sizeof(float);
+    if (WLDS) lds += ((size_t)128 * (C + 8) + (size_t)DT * 32 * 136) * sizeof(T);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)la_out_kernel<T, KS, DT, WLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int tiles = (a->n + 127) / 128;  // 128-pixel tiles per image
+    int iters = (int)(((long long)tiles * a->B) / 2048);
+    iters = iters < 1 ? 1 : (iters > 8 ? 8 : iters);
+    hipLaunchKernelGGL((la_out_kernel<T, KS, DT, WLDS>), dim3((unsigned)((tiles + iters - 1) / iters), a->B), dim3(256), lds, st, *a, iters);
     return 0;
 }
 
 }  // namespace
-
 #define DISPATCH_KS(T, FN, ARG, ST)                                   \
     switch (C / 16) {                                                 \
         case 1: FN<T, 1>(ARG, ST); break;                             \
@@ -333,8 +430,8 @@ extern "C" int dig_la_kvctx(const dig_la_kvctx_args* a, void* stream_) {
 extern "C" int dig_la_merge(const dig_la_merge_args* a, void* stream_) {
     hipStream_t st = (hipStream_t)stream_;
     DIG_CHECK(a && a->part && a->pmax && a->psum && a->ctx && a->B > 0 && a->splits > 0, DIG_EINVAL, "la_merge: bad argument");
-    if (a->dtype == DIG_BF16) hipLaunchKernelGGL(la_merge_kernel<bf16>, dim3(a->B * 4), dim3(256), 0, st, *a);
-    else hipLaunchKernelGGL(la_merge_kernel<float>, dim3(a->B * 4), dim3(256), 0, st, *a);
+    if (a->dtype == DIG_BF16) hipLaunchKernelGGL(la_merge_kernel<bf16>, dim3(a->B * 4, 4), dim3(256), 0, st, *a);
+    else hipLaunchKernelGGL(la_merge_kernel<float>, dim3(a->B * 4, 4), dim3(256), 0, st, *a);
     DIG_LAUNCH_CHECK("la_merge");
     return DIG_OK;
 }
@@ -342,7 +439,7 @@ extern "C" int dig_la_merge(const dig_la_merge_args* a, void* stream_) {
 extern "C" int dig_la_out(const dig_la_out_args* a, void* stream_) {
     hipStream_t st = (hipStream_t)stream_;
     DIG_CHECK(a && a->x && a->wq && a->mb && a->bias && a->g2 && a->out, DIG_EINVAL, "la_out: null pointer");
-    DIG_CHECK(a->B > 0 && a->n > 0 && a->n % 32 == 0 && a->dim == a->C, DIG_EINVAL, "la_out: needs n %% 32 == 0 and dim == C");
+    DIG_CHECK(a->B > 0 && a->B <= 65535 && a->n > 0 && a->n % 32 == 0 && a->dim == a->C, DIG_EINVAL, "la_out: needs n %% 32 == 0 and dim == C");
     const int C = a->C;
     if (a->dtype == DIG_BF16) { DISPATCH_KS(bf16, launch_out, a, st) } else { DISPATCH_KS(float, launch_out, a, st) }
     DIG_LAUNCH_CHECK("la_out");
