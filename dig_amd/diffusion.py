@@ -375,13 +375,8 @@ def _full_attention(p, x):
     qk = ops.linear_rows(xn, p["wqk"])  # [B,H,W,2*hid]: q | k, pixel-major
     vT = torch.empty(B, hid, n, dtype=dt, device=x.device)
     ops.gemm_nt(p["wv"], xn, vT, hid, n, C, dtype=dt, batch=B, sb=(n * C, 0), sc=(hid * n, 0))
-    S = torch.empty(B * heads, n, n, dtype=torch.float32, device=x.device)
-    ops.gemm_nt(qk, (qk, hid), S, n, n, 32, dtype=dt, lda0=2 * hid, ldb=2 * hid, ldc=n, alpha=32 ** -0.5, out_f32=True,
-                batch=B * heads, z_inner=heads, sa=(n * 2 * hid, 32), sb=(n * 2 * hid, 32), sc=(heads * n * n, n * n))
-    Pm = ops.row_softmax(S, dt)
     att = torch.empty(B, H, W, hid, dtype=dt, device=x.device)
-    ops.gemm_nt(Pm, vT, att, n, 32, n, dtype=dt, lda0=n, ldb=n, ldc=hid, batch=B * heads, z_inner=heads,
-                sa=(heads * n * n, n * n), sb=(hid * n, 32 * n), sc=(n * hid, 32))
+    call("flash_attn", qk=qk, vT=vT, out=att, B=B, n=n, heads=heads, ldqk=2 * hid, dtype=dtype_code(dt), scale=32 ** -0.5)
     return ops.linear_rows(att, p["wo"], bias=p["bo"], res=x)
 
 

@@ -133,6 +133,19 @@ typedef struct {
 } dig_row_softmax_args;
 int dig_row_softmax(const dig_row_softmax_args* a, void* stream);
 
+/* Full softmax attention with dim_head 32 (Attend.forward, attend.py:98-113, as called from ddp.py:254-262), flash
+ * style: out[b][i][h*32+e] = sum_j softmax_j(scale * q_i.k_j) v[j][e]; the [n][n] logits stay in registers.
+ *   qk : [B][n][ldqk] pixel-major, q of head h at columns h*32.., k at heads*32 + h*32..
+ *   vT : [B][heads*32][n] channel-major;  out: [B][n][heads*32].  n % 8 == 0. */
+typedef struct {
+    const void* qk;
+    const void* vT;
+    void* out;
+    int B, n, heads, ldqk, dtype;
+    float scale;
+} dig_flash_attn_args;
+int dig_flash_attn(const dig_flash_attn_args* a, void* stream);
+
 /* q.softmax(dim=-2) * scale of LinearAttention (ddp.py:224,227) on pixel-major q [rows][groups*32], in place */
 typedef struct {
     void* q;

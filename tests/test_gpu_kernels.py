@@ -172,3 +172,21 @@ def test_small_kernels():
     # layout round trip
     z = rnd("z", (2, 24, 5, 6))
     assert torch.equal(ops.nhwc_to_nchw_f32(ops.nchw_to_nhwc(z.to(DEV), torch.float32)).cpu(), z)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 4, 16), (1, 4, 24), (2, 2, 200), (1, 4, 784), (1, 3, 1024)])
+def test_flash_attn(dt, shape):
+    """dig_flash_attn vs softmax(q k^T * scale) v in fp32 (attend.py:98-113), incl. ragged key/query tiles."""
+    B, heads, n = shape
+    hid = heads * 32
+    qk = q(rnd("fa_qk", (B, n, 2 * hid), 2.0), dt)
+    v = q(rnd("fa_v", (B, n, hid)), dt)
+    qh = qk[..., :hid].reshape(B, n, heads, 32).permute(0, 2, 1, 3)
+    kh = qk[..., hid:].reshape(B, n, heads, 32).permute(0, 2, 1, 3)
+    vh = v.reshape(B, n, heads, 32).permute(0, 2, 1, 3)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * 32 ** -0.5, -1) @ vh).permute(0, 2, 1, 3).reshape(B, n, hid)
+    out = torch.empty(B, n, hid, dtype=dt, device=DEV)
+    vT = v.permute(0, 2, 1).contiguous().to(device=DEV, dtype=dt)
+    call("flash_attn", qk=qk.to(device=DEV, dtype=dt), vT=vT, out=out, B=B, n=n, heads=heads, ldqk=2 * hid, dtype=dtype_code(dt), scale=32 ** -0.5)
+    assert (out.float().cpu() - ref).abs().max() <= (2e-4 if dt == torch.float32 else 1.5e-2)
