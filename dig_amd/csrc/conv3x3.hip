@@ -12,6 +12,10 @@
 // 16-lane groups of ds_read_b128 hit 16 distinct 16-B slots (conflict-free A and B fragment reads).
 #include "common.hpp"
 
+// weight-stationary persistent variant for 64 -> 64 bf16 layers (conv3x3_ws.hip)
+bool conv3x3_ws64_eligible(int H, int W, int C0, int C1, int Cout, int groups, int dtype);
+int conv3x3_ws64_launch(const dig_conv3x3_args* a, hipStream_t stream);
+
 namespace {
 
 constexpr int TILE_W = 16;          // tile width; tile height = 4 rows per pixel-group wave
@@ -62,7 +66,10 @@ template <typename T> struct Params {
 };
 
 template <typename T, int BN, int KC, bool PF, int WPG, int WNG>
-__global__ __launch_bounds__(64 * WPG * WNG, (WPG * WNG) / 2) void conv3x3_kernel(Params<T> p) {
+#ifndef CONV_MINW
+#define CONV_MINW(WPG, WNG, BN) ((WPG * WNG) / 2)
+#endif
+__global__ __launch_bounds__(64 * WPG * WNG, CONV_MINW(WPG, WNG, BN)) void conv3x3_kernel(Params<T> p) {
     using C = ConvCfg<T, KC, WPG>;
     constexpr int NTHREADS = 64 * WPG * WNG;
     constexpr int KCP = C::KCP, HROW = C::HROW, TILE_H = C::TILE_H, HALO_H = C::HALO_H;
@@ -356,7 +363,8 @@ void conv_config(int Cout, int dtype, int* BN, int* KC, int* TH) {
 
 }  // namespace
 
-extern "C" int dig_conv3x3_tiles(int H, int W, int Cout, int dtype) {
+extern "C" int dig_conv3x3_tiles(int H, int W, int C0, int C1, int Cout, int groups, int dtype) {
+    if (conv3x3_ws64_eligible(H, W, C0, C1, Cout, groups, dtype)) return (H / 16) * (W / 16) * 4;  // per-wave partials
     int BN, KC, TH;
     conv_config(Cout, dtype, &BN, &KC, &TH);
     return cdiv(H, TH) * cdiv(W, TILE_W);
@@ -387,6 +395,8 @@ extern "C" int dig_conv3x3(const dig_conv3x3_args* a, void* stream_) {
         DIG_CHECK(cpg <= BN && BN % cpg == 0 && a->Cout % cpg == 0, DIG_EINVAL,
                   "conv3x3: GroupNorm group width %d does not tile the %d-channel block", cpg, BN);
     }
+    if (conv3x3_ws64_eligible(a->H, a->W, a->C0, a->in1 ? a->C1 : 0, a->Cout, a->stats ? a->groups : 8, a->dtype))
+        return conv3x3_ws64_launch(a, stream);
     if (a->dtype == DIG_BF16) {
         if (BN == 128) return launch<bf16, 128, 16, CONV_PF128, 4, CONV_WNG128>(a, stream);
         if (BN == 64) return launch<bf16, 64, CONV_KC64, CONV_PF64, CONV_WPG64, 1>(a, stream);

@@ -51,7 +51,7 @@ def conv3x3(x0, cw, x1=None, aff=None, up2=False, want_stats=True, groups=GN_GRO
     out = torch.empty(B, H, W, cw.Cout, dtype=x0.dtype, device=x0.device)
     stats = None
     if want_stats:
-        tiles = _lib.lib().dig_conv3x3_tiles(H, W, cw.Cout, dtype_code(x0.dtype))
+        tiles = _lib.lib().dig_conv3x3_tiles(H, W, C0, C1, cw.Cout, groups, dtype_code(x0.dtype))
         stats = torch.empty(B, groups, tiles, 2, dtype=torch.float32, device=x0.device)
     call("conv3x3", in0=_chk(x0), in1=_chk(x1) if x1 is not None else None, aff0=aff, w=cw.w, bias=cw.bias, out=out,
          stats=stats, in0_bstride=0, B=B, H=H, W=W, C0=C0, C1=C1, Cout=cw.Cout, groups=groups, up2=int(up2),

@@ -39,7 +39,7 @@ const char* dig_last_error(void);
  *             chunks = ceil(C0/KC) + ceil(C1/KC), (BN, KC) from dig_conv3x3_config(Cout, dtype);   bias: [Cout] fp32
  *   out     : [B][H][W][Cout] raw conv output (+bias)
  *   stats   : NULL, or [B][groups][tiles][2] fp32 per-tile (sum, sumsq) of out over each GroupNorm group,
- *             tiles = dig_conv3x3_tiles(H, W, Cout, dtype); reduced by dig_gn_finalize (deterministic, no atomics). */
+ *             tiles = dig_conv3x3_tiles(H, W, C0, C1, Cout, groups, dtype); reduced by dig_gn_finalize (deterministic, no atomics). */
 typedef struct {
     const void* in0;
     const void* in1;
@@ -51,7 +51,7 @@ typedef struct {
     long long in0_bstride; /* elements between images of in0; 0 = dense (Hi*Wi*C0) */
     int B, H, W, C0, C1, Cout, groups, up2, dtype;
 } dig_conv3x3_args;
-int dig_conv3x3_tiles(int H, int W, int Cout, int dtype);
+int dig_conv3x3_tiles(int H, int W, int C0, int C1, int Cout, int groups, int dtype);
 int dig_conv3x3_config(int Cout, int dtype, int* BN, int* KC);
 int dig_conv3x3(const dig_conv3x3_args* a, void* stream);
 

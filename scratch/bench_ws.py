@@ -1,0 +1,24 @@
+import sys, os, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dig_amd import ops
+dt = torch.bfloat16
+DEV = 'cuda'
+B, H, W = 32, 256, 256
+x = torch.randn(B, H, W, 64, device=DEV).to(dt)
+cw = ops.ConvWeight(torch.randn(64, 64, 3, 3, device=DEV) * 0.05, torch.zeros(64, device=DEV), dt)
+aff = torch.ones(B, 64, 2, device=DEV)
+def run(tag, pro=False, iters=10):
+    a = aff if pro else None
+    for _ in range(2): ops.conv3x3(x, cw, aff=a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): ops.conv3x3(x, cw, aff=a)
+    e1.record(); torch.cuda.synchronize()
+    print(f"{tag:28s} pro={int(pro)} {e0.elapsed_time(e1)/iters*1e3:8.1f} us", flush=True)
+base = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+for skip in [0, 1, 2, 4, 8, 14, 15]:
+    os.environ["DIG_WS_SKIP"] = str(skip | base)
+    run(f"skip={skip | base}")
+os.environ["DIG_WS_SKIP"] = str(base)
+run("pro", pro=True)

@@ -1,0 +1,22 @@
+import sys, os, ctypes, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dig_amd import ops, _lib
+dt = torch.bfloat16
+DEV = 'cuda'
+B, H, W = 32, 256, 256
+x = torch.randn(B, H, W, 64, device=DEV).to(dt)
+cw = ops.ConvWeight(torch.randn(64, 64, 3, 3, device=DEV) * 0.05, torch.zeros(64, device=DEV), dt)
+aff = torch.ones(B, 64, 2, device=DEV) if len(sys.argv) > 1 else None
+for _ in range(3): ops.conv3x3(x, cw, aff=aff)
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * (8 * 64 * 8))()
+L = ctypes.CDLL(_lib.LIB_PATH)
+print("rc", L.dig_debug_ws_trace(buf))
+t0 = min(buf[(w * 64 + 0) * 8] for w in range(8))
+for ph in range(0, 12):
+    row = []
+    for w in (0, 4):
+        a, b, c, s3, s4, s5 = (buf[(w * 64 + ph) * 8 + i] - t0 for i in range(6))
+        stage = (ph - 1 - (w >> 2)) & 1
+        row.append(f"w{w}: {a:7d} +{b-a:6d} +{c-b:6d}" + (f" [gl {s3-a:5d} E1 {s4-s3:5d} E2 {s5-s4:5d} ls {b-s5:5d}]" if stage else " " * 41))
+    print(f"ph{ph-1:3d} ", " | ".join(row))

@@ -190,3 +190,34 @@ def test_flash_attn(dt, shape):
     vT = v.permute(0, 2, 1).contiguous().to(device=DEV, dtype=dt)
     call("flash_attn", qk=qk.to(device=DEV, dtype=dt), vT=vT, out=out, B=B, n=n, heads=heads, ldqk=2 * hid, dtype=dtype_code(dt), scale=32 ** -0.5)
     assert (out.float().cpu() - ref).abs().max() <= (2e-4 if dt == torch.float32 else 1.5e-2)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 48, 0), (1, 16, 16, 0), (3, 64, 32, 0), (1, 112, 112, 0), (3, 64, 32, 3), (2, 48, 80, 1), (5, 32, 32, 2)])
+def test_conv3x3_weight_stationary_64(shape, monkeypatch):
+    """The persistent weight-stationary 64->64 bf16 variant (conv3x3_ws.hip): plain + GroupNorm partials (4 per tile),
+    GroupNorm-apply + SiLU prologue, nearest-x2 addressing.  The last cases force a tiny grid (DIG_WS_GRID) so that
+    every block walks many tiles, across image boundaries, with an odd tile count for one of the two wave groups."""
+    dt = torch.bfloat16
+    B, H, W, grid = shape
+    if grid:
+        monkeypatch.setenv("DIG_WS_GRID", str(grid))
+    x = q(rnd("wsx", (B, 64, H, W)), dt)
+    w, b = q(rnd("wsw", (64, 64, 3, 3), (3.0 / (9 * 64)) ** 0.5), dt), rnd("wsb", (64,), 0.1)
+    cw = ops.ConvWeight(w.to(DEV), b.to(DEV), dt)
+    ref = F.conv2d(x, w, b, padding=1)
+    y, st = ops.conv3x3(nhwc(x, dt), cw)
+    assert st.shape[2] == (H // 16) * (W // 16) * 4
+    assert (nchw(y) - ref).abs().max() <= tol(dt, ref)
+    st = st.cpu().double().sum(2)
+    g = ref.reshape(B, 8, -1).double()
+    assert torch.allclose(st[..., 0], g.sum(-1), rtol=1e-3, atol=1e-2 * g.shape[-1] ** 0.5)
+    assert torch.allclose(st[..., 1], (g * g).sum(-1), rtol=2e-3)
+    aff = torch.stack([1.0 + 0.3 * rnd("wsa", (B, 64)), 0.2 * rnd("wsbb", (B, 64))], -1)
+    xin = F.silu(x * aff[..., 0][:, :, None, None] + aff[..., 1][:, :, None, None])
+    ref = F.conv2d(q(xin, dt), w, b, padding=1)
+    y, _ = ops.conv3x3(nhwc(x, dt), cw, aff=aff.to(DEV).contiguous())
+    assert (nchw(y) - ref).abs().max() <= 2 * tol(dt, ref)
+    if H <= 64:
+        ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1)
+        y, _ = ops.conv3x3(nhwc(x, dt), cw, up2=True, want_stats=False)
+        assert (nchw(y) - ref).abs().max() <= tol(dt, ref)
