@@ -349,7 +349,7 @@ def _linear_attention(p, x):
     dt = x.dtype
     dc = dtype_code(dt)
     tiles = (n + 63) // 64
-    splits = max(1, min(64, tiles // 4, max(1, 2048 // B)))
+    splits = max(1, min(64, tiles // 4, max(1, 512 // B)))  # ~512 blocks in pass A; fewer, longer splits merge cheaper
     part = torch.empty(B, splits, 4, 32, 32, dtype=torch.float32, device=x.device)
     pmax = torch.empty(B, splits, 4, 32, dtype=torch.float32, device=x.device)
     psum = torch.empty(B, splits, 4, 32, dtype=torch.float32, device=x.device)
