@@ -299,7 +299,7 @@ def _resnet(p, x0, x1, ss_all, debug=None):
         assert x1 is None
         return ops.gn_silu_add(c2, aff2, res=x0)
     wr, br = p["res"]
-    return ops.linear_rows(x0, wr, bias=br, x1=x1, gsrc=c2, gaff=aff2, rows_per_img=hw)
+    return ops.res_tail(x0, wr, br, x1, c2, aff2, hw)
 
 
 def _linear_attention_unfused(p, x):

@@ -126,6 +126,21 @@ def linear_rows(x, w, bias=None, res=None, gelu=False, out_f32=False, x1=None, g
     return y
 
 
+def res_tail(x0, w, bias, x1, gsrc, gaff, rows_per_img):
+    """ResnetBlock tail with a channel-changing shortcut: res_conv([x0 | x1]) + SiLU(GroupNorm-apply(gsrc)).
+    Streaming kernel where the shape is supported (small K, N), otherwise the general GEMM with the same epilogue."""
+    K0 = x0.shape[-1]
+    K1 = x1.shape[-1] if x1 is not None else 0
+    N = w.shape[0]
+    M = x0.numel() // K0
+    if M % 32 == 0 and rows_per_img % 32 == 0 and _lib.lib().dig_pw_res_supported(K0, K1, N, dtype_code(x0.dtype)):
+        out = torch.empty(*x0.shape[:-1], N, dtype=x0.dtype, device=x0.device)
+        call("pw_res", x0=_chk(x0), x1=_chk(x1) if x1 is not None else None, w=_chk(w), bias=bias, gsrc=_chk(gsrc), gaff=gaff,
+             out=out, M=M, K0=K0, K1=K1, N=N, rows_per_img=rows_per_img, dtype=dtype_code(x0.dtype))
+        return out
+    return linear_rows(x0, w, bias=bias, x1=x1, gsrc=gsrc, gaff=gaff, rows_per_img=rows_per_img)
+
+
 def downsample_conv(x, w, bias):
     """Pixel-unshuffle (2x2) + conv1x1; w packed [Cout, 4C] with K ordered (p1, p2, c)."""
     B, H, W, C = x.shape

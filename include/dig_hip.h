@@ -112,6 +112,24 @@ typedef struct {
 } dig_gn_silu_add_args;
 int dig_gn_silu_add(const dig_gn_silu_add_args* a, void* stream);
 
+/* ResnetBlock tail with a channel-changing shortcut (ddp.py:190-194), streaming kernel for small K and N (the 256x256
+ * and 128x128 levels):  out[m][:] = [x0 | x1][m][:] @ w^T + bias + SiLU(gaff.a * gsrc[m][:] + gaff.b).
+ *   x0 [M][K0], x1 [M][K1] (or NULL), w [N][K0+K1], gsrc [M][N], gaff [M / rows_per_img][N][2], out [M][N].
+ * dig_pw_res_supported tells whether (K0, K1, N, dtype) is handled; otherwise use dig_gemm_nt with the same epilogue. */
+typedef struct {
+    const void* x0;
+    const void* x1;
+    const void* w;
+    const float* bias;
+    const void* gsrc;
+    const float* gaff;
+    void* out;
+    long long M;
+    int K0, K1, N, rows_per_img, dtype;
+} dig_pw_res_args;
+int dig_pw_res_supported(int K0, int K1, int N, int dtype);
+int dig_pw_res(const dig_pw_res_args* a, void* stream);
+
 /* RMSNorm over channels per pixel (ddp.py:108-114): out = x / max(||x||,1e-12) * g * sqrt(C) [+ res] */
 typedef struct {
     const void* x;

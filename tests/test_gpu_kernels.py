@@ -221,3 +221,22 @@ def test_conv3x3_weight_stationary_64(shape, monkeypatch):
         ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1)
         y, _ = ops.conv3x3(nhwc(x, dt), cw, up2=True, want_stats=False)
         assert (nchw(y) - ref).abs().max() <= tol(dt, ref)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32, 64, 64, 64), (3, 16, 32, 128, 64, 128), (1, 64, 96, 64, 64, 64)])
+def test_pw_res_tail(shape):
+    """dig_pw_res (streaming ResnetBlock tail) vs conv1x1([x0|x1]) + SiLU(a*h2+b) in fp32, and vs the general GEMM path."""
+    dt = torch.bfloat16
+    B, H, W, K0, K1, N = shape
+    x0, x1 = q(rnd("pwx0", (B, H, W, K0)), dt), q(rnd("pwx1", (B, H, W, K1)), dt)
+    h2 = q(rnd("pwh2", (B, H, W, N), 2.0), dt)
+    w = q(rnd("pww", (N, K0 + K1), (K0 + K1) ** -0.5), dt)
+    bias = rnd("pwb", (N,), 0.1)
+    aff = torch.stack([1.0 + 0.3 * rnd("pwa", (B, N)), 0.2 * rnd("pwab", (B, N))], -1).contiguous()
+    ref = torch.cat([x0, x1], -1) @ w.t() + bias + F.silu(h2 * aff[:, None, None, :, 0] + aff[:, None, None, :, 1])
+    d = lambda t: t.to(device=DEV, dtype=dt).contiguous()
+    assert ops._lib.lib().dig_pw_res_supported(K0, K1, N, dtype_code(dt)) == 1
+    y = ops.res_tail(d(x0), d(w), bias.to(DEV), d(x1), d(h2), aff.to(DEV), H * W)
+    assert (y.float().cpu() - ref).abs().max() <= tol(dt, ref)
+    y2 = ops.linear_rows(d(x0), d(w), bias=bias.to(DEV), x1=d(x1), gsrc=d(h2), gaff=aff.to(DEV), rows_per_img=H * W)
+    assert (y.float() - y2.float()).abs().max().item() <= tol(dt, ref)
