@@ -84,8 +84,12 @@ def main():
         out = orig_conv(x0_, cw, x1=x1, aff=aff, up2=up2, want_stats=want_stats, groups=groups)
         e1.record()
         Bc, Hc, Wc, Co = out[0].shape
-        cls = "conv3x3_bn128" if Co % 128 == 0 else ("conv3x3_bn64" if Co > 32 else "conv3x3_bn32")
-        conv_log.append((cls, 2.0 * Bc * Hc * Wc * Co * (cw.C0 + cw.C1) * 9, e0, e1))
+        if Co == 64 and cw.C0 == 64 and cw.C1 == 0 and Hc % 16 == 0 and Wc % 16 == 0 and out[0].dtype == torch.bfloat16:
+            cls = "conv3x3_ws64"  # weight-stationary persistent kernel (conv3x3_ws.hip)
+        else:
+            cls = "conv3x3_bn128" if Co % 128 == 0 else ("conv3x3_bn64" if Co > 32 else "conv3x3_bn32")
+        conv_log.append((cls, 2.0 * Bc * Hc * Wc * Co * (cw.C0 + cw.C1) * 9, e0, e1,
+                         2.0 * Bc * Hc * Wc * ((cw.C0 + cw.C1) / (4 if up2 else 1) + Co)))  # algorithmic HBM bytes (bf16/fp32 scaled below)
         return out
 
     ops.conv3x3 = conv_timed
@@ -121,22 +125,31 @@ def main():
 
     # ---- roofline of the dominant kernel class
     per_cls = {}
-    for cls, fl, e0, e1 in conv_log:
-        d = per_cls.setdefault(cls, [0.0, 0.0, 0])
+    esz = 2 if dt == torch.bfloat16 else 4
+    for cls, fl, e0, e1, by in conv_log:
+        d = per_cls.setdefault(cls, [0.0, 0.0, 0, 0.0])
         d[0] += fl
         d[1] += e0.elapsed_time(e1) * 1e-3
         d[2] += 1
+        d[3] += by * esz / 2
     dom = max(per_cls, key=lambda k: per_cls[k][1]) if per_cls else None
     peak = PEAK_BF16_TFLOPS if dt == torch.bfloat16 else PEAK_F32_TFLOPS
     roof = None
     if dom:
-        fl, sec, n = per_cls[dom]
+        fl, sec, n, by = per_cls[dom]
         ach = fl / sec / 1e12
+        # HBM bytes per launch of this kernel class from the committed PMC passes (tools/pmc_traffic.py; bf16, B=32, 256x256 only)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath) and dt == torch.bfloat16 and B == 32 and S == 256:
+            with open(tpath) as f:
+                traffic = json.load(f)["classes"].get(dom, {}).get("hbm_bytes_per_launch")
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": None, "launches": n, "avg_launch_ms": round(1e3 * sec / n, 4),
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
+                "algorithmic_bytes_per_launch_avg": round(by / n), "launches": n, "avg_launch_ms": round(1e3 * sec / n, 4),
                 "flops_per_launch_avg": fl / n,
                 "classes": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(1e3 * v[1] / args.steps, 3),
-                                "launches_per_step": v[2] // args.steps} for k, v in per_cls.items()}}
+                                "launches_per_step": v[2] // args.steps, "hbm_algorithmic_GBps": round(v[3] / v[1] / 1e9, 1)} for k, v in per_cls.items()}}
     gflop = GFLOP_PER_MAP.get(S)
     whole = {"tflops": round(maps_per_s / world * gflop / 1e3, 2), "frac_of_mfma_peak": round(maps_per_s / world * gflop / 1e3 / peak, 4)} if gflop else None
 
