@@ -15,6 +15,9 @@
 // weight-stationary persistent variant for 64 -> 64 bf16 layers (conv3x3_ws.hip)
 bool conv3x3_ws64_eligible(int H, int W, int C0, int C1, int Cout, int groups, int dtype);
 int conv3x3_ws64_launch(const dig_conv3x3_args* a, hipStream_t stream);
+// double-buffered 8-wave variant for the wide bf16 layers (conv3x3_db.hip): 32x16-pixel tiles
+bool conv3x3_db_eligible(int C0, int C1, int Cout, int dtype);
+int conv3x3_db_launch(const dig_conv3x3_args* a, hipStream_t stream);
 
 namespace {
 
@@ -365,9 +368,14 @@ void conv_config(int Cout, int dtype, int* BN, int* KC, int* TH) {
 
 extern "C" int dig_conv3x3_tiles(int H, int W, int C0, int C1, int Cout, int groups, int dtype) {
     if (conv3x3_ws64_eligible(H, W, C0, C1, Cout, groups, dtype)) return (H / 16) * (W / 16) * 4;  // per-wave partials
+    if (conv3x3_db_eligible(C0, C1, Cout, dtype)) return cdiv(H, 32) * cdiv(W, TILE_W);                // 32x16-pixel tiles
     int BN, KC, TH;
     conv_config(Cout, dtype, &BN, &KC, &TH);
     return cdiv(H, TH) * cdiv(W, TILE_W);
+}
+
+extern "C" int dig_conv3x3_wlayout(int C0, int C1, int Cout, int dtype) {
+    return conv3x3_db_eligible(C0, C1, Cout, dtype) ? 1 : 0;
 }
 
 extern "C" int dig_conv3x3_config(int Cout, int dtype, int* BN, int* KC) {
@@ -397,6 +405,7 @@ extern "C" int dig_conv3x3(const dig_conv3x3_args* a, void* stream_) {
     }
     if (conv3x3_ws64_eligible(a->H, a->W, a->C0, a->in1 ? a->C1 : 0, a->Cout, a->stats ? a->groups : 8, a->dtype))
         return conv3x3_ws64_launch(a, stream);
+    if (conv3x3_db_eligible(a->C0, a->in1 ? a->C1 : 0, a->Cout, a->dtype)) return conv3x3_db_launch(a, stream);
     if (a->dtype == DIG_BF16) {
         if (BN == 128) return launch<bf16, 128, 16, CONV_PF128, 4, CONV_WNG128>(a, stream);
         if (BN == 64) return launch<bf16, 64, CONV_KC64, CONV_PF64, CONV_WPG64, 1>(a, stream);

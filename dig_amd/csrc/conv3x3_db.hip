@@ -3,7 +3,8 @@
 // Same tiling idea as conv3x3.hip (one 18x18 halo tile of KC = 16 input channels serves all 9 taps), rebuilt around the
 // data movement that bounds those layers: a 16x16-pixel x 128-channel tile re-reads its whole [9][128][Cin] weight
 // panel from L2, 36 KB per 16-channel chunk.
-//   * 512 threads = 8 waves (4 pixel groups x 2 channel halves, 64 px x 64 ch each), ONE block per CU;
+//   * 32x16-pixel x 128-channel tile per block, so a weight chunk is shared by twice as many MFMAs;
+//   * 512 threads = 8 waves (8 pixel groups of 4 rows, 64 px x 128 ch each), ONE block per CU;
 //   * two LDS buffers of {halo chunk, weight chunk}; the weight chunk of step c+1 goes global -> LDS directly
 //     (global_load_lds_dwordx4, no registers, no LDS store instructions) while step c is multiplied; the halo chunk
 //     still passes through registers (concat / nearest-x2 / GroupNorm-apply + SiLU prologue happen there);
@@ -18,14 +19,24 @@ namespace {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
-constexpr int BN = 128, KC = 16, KCP = KC + 8, HALO_W = 18, HALO_H = 18;
+constexpr int BN = 128, KC = 16, KCP = KC + 8, TILE_H = 32, HALO_W = 18, HALO_H = TILE_H + 2;
 constexpr int HROW = 512;                               // halo row stride in elements (18 * 24 * 2 B = 864 -> 1024 B)
-constexpr int HALO_BYTES = HALO_H * HROW * 2;           // 18432
+constexpr int HALO_BYTES = HALO_H * HROW * 2;           // 34816
 constexpr int WSLAB_BYTES = 9 * BN * KC * 2;            // 36864
-constexpr int BUF_BYTES = HALO_BYTES + WSLAB_BYTES;     // 55296
-constexpr int DB_LDS = 2 * BUF_BYTES;                   // 110592
-constexpr int NTHREADS = 512, NH = 2;                   // halo vectors per thread per chunk (648 of 1024 slots used)
+constexpr int BUF_BYTES = HALO_BYTES + WSLAB_BYTES;     // 71680
+constexpr int DB_LDS = 2 * BUF_BYTES;                   // 143360
+constexpr int NTHREADS = 512, NH = 3;                   // halo vectors per thread per chunk (34*18*2 = 1224 of 1536 slots used)
 constexpr int OS = BN + 4;                              // fp32 staging row stride of the epilogue
+
+#ifndef DB_TAP_ISSUE
+#define DB_TAP_ISSUE 0
+#endif
+#ifndef DB_TAP_STORE_A
+#define DB_TAP_STORE_A 7
+#endif
+#ifndef DB_TAP_STORE_B
+#define DB_TAP_STORE_B 5
+#endif
 
 #ifdef DB_TRACE
 __device__ unsigned long long db_trace[8 * 64 * 8];
@@ -50,21 +61,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_db_kernel(DbParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pg = wave & 3, ng = wave >> 2;
+    const int pg = wave;  // pixel group: tile rows 4pg..4pg+3; every wave computes all 128 channels
     const int r = lane & 31, hf = lane >> 5;
     const int tiles = p.tiles_x * p.tiles_y;
     const int b = blockIdx.x / tiles, tile = blockIdx.x % tiles;
-    const int ty0 = (tile / p.tiles_x) * 16, tx0 = (tile % p.tiles_x) * 16;
+    const int ty0 = (tile / p.tiles_x) * TILE_H, tx0 = (tile % p.tiles_x) * 16;
     const int n0 = blockIdx.y * BN;
     const int Hs = p.up2 ? p.H >> 1 : p.H, Ws = p.up2 ? p.W >> 1 : p.W;
     const int nch0 = p.C[0] / KC, nch1 = p.C[1] / KC, nch = nch0 + nch1;
     const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w) + (size_t)blockIdx.y * nch * WSLAB_BYTES;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][4];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 8; i++)
 #pragma unroll
-        for (int e = 0; e < 16; e++) acc[i >> 1][i & 1][e] = 0.f;
+        for (int e = 0; e < 16; e++) acc[i >> 2][i & 3][e] = 0.f;
 
     // ---- halo staging through registers.  Everything that does not depend on the chunk is computed once: the source
     // pixel of each of the thread's two vectors (clamped into the image; out-of-image pixels are zeroed at the LDS
@@ -145,26 +156,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_db_kernel(DbParams p) {
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             const int ky = tap / 3, kx = tap - ky * 3;
-            Frag<bf16> fa[2], fb[2];
+            Frag<bf16> fa[2], fb[4];
 #pragma unroll
             for (int mr = 0; mr < 2; mr++) {
                 const int py = pg * 4 + mr * 2 + (r >> 4), px = r & 15;
                 frag_load<bf16>(fa[mr], halo + (py + ky) * HROW + (px + kx) * KCP + hf * 8);
             }
 #pragma unroll
-            for (int nr = 0; nr < 2; nr++)
-                fb[nr].v = *reinterpret_cast<const bf16x8*>(wl + (tap * BN + (ng * 2 + nr) * 32 + r) * 32 + ((hf ^ bsw) << 4));
+            for (int nr = 0; nr < 4; nr++)
+                fb[nr].v = *reinterpret_cast<const bf16x8*>(wl + (tap * BN + nr * 32 + r) * 32 + ((hf ^ bsw) << 4));
 #pragma unroll
             for (int mr = 0; mr < 2; mr++)
 #pragma unroll
-                for (int nr = 0; nr < 2; nr++) mma16<bf16>(acc[mr][nr], fa[mr], fb[nr]);
-            if (tap == 1 && more) {  // next chunk's loads go out once the MFMA pipe has work queued behind the barrier
+                for (int nr = 0; nr < 4; nr++) mma16<bf16>(acc[mr][nr], fa[mr], fb[nr]);
+            if (tap == DB_TAP_ISSUE && more) {  // next chunk's loads go out once the MFMA pipe has work queued behind the barrier
                 wload(ci + 1, nxt);
                 gload(ci + 1);
             }
+            // the halo registers go to LDS inside the MFMA sequence (the partner wave of the SIMD keeps the pipe busy
+            // meanwhile); the two wave halves do it at different taps so that they do not all leave the pipe at once
+            if (tap == (wave < 4 ? DB_TAP_STORE_A : DB_TAP_STORE_B) && more) lstore(ci + 1, nxt);
         }
         DB_STAMP(2)
-        if (more) lstore(ci + 1, nxt);
         DB_STAMP(3)
         __syncthreads();
         DB_STAMP(4)
@@ -180,12 +193,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_db_kernel(DbParams p) {
     // ---- epilogue: +bias, GroupNorm partials from the fp32 accumulators, output tile transposed through LDS (fp32, one
     // 128-pixel half at a time) so that HBM sees 16-byte stores of 8 consecutive channels.
     float* ot = reinterpret_cast<float*>(smem);
-    float cs[2] = {0.f, 0.f}, css[2] = {0.f, 0.f};
+    float cs[4] = {0.f, 0.f, 0.f, 0.f}, css[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int mr = 0; mr < 2; mr++) {
 #pragma unroll
-        for (int nr = 0; nr < 2; nr++) {
-            const int nl = (ng * 2 + nr) * 32 + r;
+        for (int nr = 0; nr < 4; nr++) {
+            const int nl = nr * 32 + r;
             const float bias = p.bias[n0 + nl];
 #pragma unroll
             for (int e = 0; e < 16; e++) {
@@ -200,7 +213,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_db_kernel(DbParams p) {
             }
         }
         __syncthreads();
-        for (int idx = tid; idx < 128 * (BN / 8); idx += NTHREADS) {
+        for (int idx = tid; idx < 256 * (BN / 8); idx += NTHREADS) {
             const int pl = idx / (BN / 8), v8 = idx - pl * (BN / 8);
             const int wv = pl >> 5, row = pl & 31;
             const int Y = ty0 + wv * 4 + mr * 2 + (row >> 4), X = tx0 + (row & 15);
@@ -216,10 +229,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_db_kernel(DbParams p) {
     }
     if (p.stats != nullptr) {
         float* st = reinterpret_cast<float*>(smem);  // [pixel group][half][BN][2], then [BN][2]
-        float* col = st + 4 * 2 * BN * 2;
+        float* col = st + 8 * 2 * BN * 2;
 #pragma unroll
-        for (int nr = 0; nr < 2; nr++) {
-            float* d = st + (((pg * 2 + hf) * BN) + (ng * 2 + nr) * 32 + r) * 2;
+        for (int nr = 0; nr < 4; nr++) {
+            float* d = st + (((pg * 2 + hf) * BN) + nr * 32 + r) * 2;
             d[0] = cs[nr];
             d[1] = css[nr];
         }
@@ -227,7 +240,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_db_kernel(DbParams p) {
         if (tid < BN) {
             float s = 0.f, ss = 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {  // fixed order -> deterministic
+            for (int k = 0; k < 16; k++) {  // fixed order -> deterministic
                 s += st[(k * BN + tid) * 2];
                 ss += st[(k * BN + tid) * 2 + 1];
             }
@@ -274,7 +287,7 @@ int conv3x3_db_launch(const dig_conv3x3_args* a, hipStream_t stream) {
     p.bstride0 = a->in0_bstride > 0 ? a->in0_bstride : (long long)(a->up2 ? (a->H / 2) * (a->W / 2) : a->H * a->W) * a->C0;
     p.B = a->B; p.H = a->H; p.W = a->W; p.Cout = a->Cout; p.groups = a->groups; p.up2 = a->up2;
     p.tiles_x = cdiv(a->W, 16);
-    p.tiles_y = cdiv(a->H, 16);
+    p.tiles_y = cdiv(a->H, TILE_H);
     static bool attr_set[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);

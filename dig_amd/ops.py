@@ -37,6 +37,10 @@ class ConvWeight:
         w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, (-Co) % BN))  # pad Cout to a multiple of BN
         nt = w.shape[0] // BN
         w = w.reshape(nt, BN, 9, nch, KC).permute(0, 3, 2, 1, 4).contiguous()
+        if _lib.lib().dig_conv3x3_wlayout(C0, C1, Co, dtype_code(dtype)) == 1:
+            assert KC == 16
+            rows = (torch.arange(BN, device=w.device) >> 3) & 1 == 1
+            w[:, :, :, rows, :] = torch.cat([w[:, :, :, rows, 8:], w[:, :, :, rows, :8]], -1)
         self.w = w.to(dtype)
         self.bias = bias.detach().float().contiguous()
         self.Cout, self.C0, self.C1, self.dtype = Co, C0, C1, dtype

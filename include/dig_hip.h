@@ -52,6 +52,10 @@ typedef struct {
     int B, H, W, C0, C1, Cout, groups, up2, dtype;
 } dig_conv3x3_args;
 int dig_conv3x3_tiles(int H, int W, int C0, int C1, int Cout, int groups, int dtype);
+/* Row layout of the packed weight slabs for this layer: 0 = plain [..][BN][KC]; 1 = the two 16-byte halves of a row are
+ * swapped when bit 3 of the row index is set (the LDS image of the double-buffered wide-layer kernel, which copies the
+ * slabs global -> LDS without touching them). */
+int dig_conv3x3_wlayout(int C0, int C1, int Cout, int dtype);
 int dig_conv3x3_config(int Cout, int dtype, int* BN, int* KC);
 int dig_conv3x3(const dig_conv3x3_args* a, void* stream);
 

@@ -17,5 +17,5 @@ def run(B, H, W, Ci, Co, pro=False, C1=0, iters=10):
     ms = e0.elapsed_time(e1) / iters
     fl = 2.0 * B * H * W * Co * (Ci + C1) * 9
     print(f"{os.environ.get('DIG_HIP_LIB','default')[-14:]:>14} B{B} {H}x{W} {Ci}+{C1}->{Co} pro={int(pro)}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF")
-for args in [(32,256,256,64,64,False),(32,256,256,64,64,True),(32,256,256,64,64,False,64),(32,128,128,128,128,False),(32,64,64,256,256,False),(32,32,32,512,512,False),(32,32,32,512,512,True)]:
+for args in [(32,128,128,128,128,False),(32,64,64,256,256,False),(32,32,32,512,512,False),(32,32,32,512,512,True),(32,32,32,768,512,False)]:
     run(*args)
