@@ -15,7 +15,7 @@ import sys
 
 CLASSES = [
     ("conv3x3_ws64", r"conv3x3_ws64_kernel"),
-    ("conv3x3_bn128", r"conv3x3_kernelIDF16bLi128"),
+    ("conv3x3_bn128", r"conv3x3_db_kernel|conv3x3_kernelIDF16bLi128"),  # wide layers: double-buffered kernel
     ("conv3x3_bn64", r"conv3x3_kernelIDF16bLi64"),
     ("conv3x3_bn32", r"conv3x3_kernelIDF16bLi32"),
     ("pw_res_k128_n64", r"pw_res_kernel<8"),
