@@ -36,7 +36,6 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--t", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--profile-kernels", action="store_true", help="per-kernel-class HIP-event breakdown (stderr)")
     args = ap.parse_args()
 
@@ -109,12 +108,20 @@ def main():
     for _ in range(max(args.warmup, 1)):
         step()
     sync_all()
-    state["on"] = True
+    # timed region: exactly K steps, nothing but the hot path on the stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
+    # second pass of K steps with a HIP event pair around every conv3x3 launch (the roofline numbers).  The 86 event
+    # records per step cost ~0.9 ms of stream bubbles, so this pass is kept out of `value` and reported beside it.
+    state["on"] = True
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed_instr = time.perf_counter() - t1
     state["on"] = False
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -147,6 +154,8 @@ def main():
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
                 "algorithmic_bytes_per_launch_avg": round(by / n), "launches": n, "avg_launch_ms": round(1e3 * sec / n, 4),
+                "measured": f"HIP events on the launch stream around every conv3x3 launch, second pass of {args.steps} steps "
+                            f"({1e3 * elapsed_instr / args.steps:.3f} ms/step with the event records in the stream)",
                 "flops_per_launch_avg": fl / n,
                 "classes": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(1e3 * v[1] / args.steps, 3),
                                 "launches_per_step": v[2] // args.steps, "hbm_algorithmic_GBps": round(v[3] / v[1] / 1e9, 1)} for k, v in per_cls.items()}}
