@@ -117,6 +117,43 @@ def test_gemm_concat_gnres_unshuffle_nchw(dt):
     assert (out.cpu() - ref).abs().max() <= tol(dt, ref)
 
 
+@pytest.mark.parametrize("shape", [(700, 256, 128, 256, 100), (130, 512, 256, 520, 65), (260, 64, 0, 64, 260), (1100, 96, 32, 40, 550),
+                                   (2048, 128, 0, 128, 1024), (90, 1024, 512, 72, 30)])
+def test_gemm_dma_pipeline(shape):
+    """bf16 GEMMs with K % 32 == 0 take the multi-stage LDS-DMA kernel: 1..48 K steps (pipeline fill, steady state and drain),
+    ragged M and N tiles, the concat loader and the GroupNorm+SiLU / bias epilogue, against F.linear in fp32."""
+    M, K0, K1, N, rows = shape
+    dt = torch.bfloat16
+    K = K0 + K1
+    x0 = q(rnd("dx0", (M, K0)), dt)
+    x1 = q(rnd("dx1", (M, K1)), dt) if K1 else None
+    w, b = q(rnd("dw", (N, K), K ** -0.5), dt), rnd("db", (N,), 0.1)
+    raw = q(rnd("draw", (M, N)), dt)
+    aff = torch.stack([1.0 + 0.3 * rnd("da", (M // rows, N)), 0.2 * rnd("dbb", (M // rows, N))], -1)
+    xin = torch.cat([x0, x1], 1) if K1 else x0
+    ab = aff.repeat_interleave(rows, 0)
+    ref = F.linear(xin, w, b) + F.silu(raw * ab[..., 0] + ab[..., 1])
+    dev = lambda t: t.to(device=DEV, dtype=dt)
+    y = ops.linear_rows(dev(x0), dev(w), bias=b.to(DEV), x1=dev(x1) if K1 else None, gsrc=dev(raw), gaff=aff.to(DEV).contiguous(), rows_per_img=rows)
+    assert (y.float().cpu() - ref).abs().max() <= tol(dt, ref)
+    y32 = ops.linear_rows(dev(x0), dev(w), x1=dev(x1) if K1 else None, out_f32=True)
+    assert (y32.cpu() - F.linear(xin, w)).abs().max() <= 2e-3 * max(1.0, float(ref.abs().max()))  # bf16 products, fp32 accumulate
+
+
+@pytest.mark.parametrize("N", [1, 3, 4])
+def test_final_conv_stream(N):
+    """final_conv (ddp.py:377): K = 64 bf16 rows -> N <= 4 fp32 NCHW planes takes the streaming kernel inside dig_gemm_nt."""
+    B, H, W, C = 3, 16, 24, 64
+    dt = torch.bfloat16
+    x = q(rnd("fx", (B, C, H, W)), dt)
+    w, b = q(rnd("fw", (N, C, 1, 1), 0.2), dt), rnd("fb", (N,), 0.1)
+    ref = F.conv2d(x, w, b)
+    out = torch.empty(B, N, H, W, dtype=torch.float32, device=DEV)
+    ops.gemm_nt(nhwc(x, dt), w.reshape(N, C).to(device=DEV, dtype=dt), out, B * H * W, N, C, dtype=dt, bias=b.to(DEV).contiguous(),
+                out_f32=True, nchw_hw=H * W)
+    assert (out.cpu() - ref).abs().max() <= 1e-4 * max(1.0, float(ref.abs().max()))  # bf16 products, fp32 accumulate
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_gn_finalize_and_apply(dt):
     B, C, H, W = 2, 32, 20, 24
