@@ -123,7 +123,7 @@ __device__ __forceinline__ void kv_tile(const T* xs, const Frag<T>* fk, const Fr
 }
 
 template <typename T, int KS, bool WREG>
-__global__ __launch_bounds__(256, (KS <= 4 ? 2 : 1)) void la_kv_ctx_kernel(dig_la_kvctx_args a) {
+__global__ __launch_bounds__(256, (KS * (int)sizeof(T) <= 16 ? 2 : 1)) void la_kv_ctx_kernel(dig_la_kvctx_args a) {
     constexpr int C = KS * 16, CP = C + 8, TP = 64;
     constexpr int LPR = C / 8;                       // lanes that share one pixel row while staging
     constexpr int NV = (TP * LPR + 255) / 256;       // 16-byte vectors per thread per tile
@@ -216,37 +216,39 @@ template <typename T> __global__ __launch_bounds__(256) void la_merge_kernel(dig
 
 // ------------------------------------------------------------------------------------------------------------
 // pass B.  One wave owns 32 pixels at a time (its own 32 rows of the LDS tile - no block barriers in the loop) and
-// walks `iters` such sub-tiles of one image.  For C <= 64 (WLDS) the q weights and this image's M_b sit in LDS for
-// the block's lifetime, M_b with the columns of every 16-group permuted so that an accumulator-ordered k-fragment
+// walks `iters` such sub-tiles of one image.  Where they fit (WQL / MBL, see launch_out) the q weights and this image's
+// M_b sit in LDS for the block's lifetime, M_b with the columns of every 16-group permuted so that an accumulator-ordered k-fragment
 // is one 16-byte read.
-template <typename T, int KS, int DT, bool WLDS>
-__global__ __launch_bounds__(256, (KS <= 8 ? 2 : 1)) void la_out_kernel(dig_la_out_args a, int iters) {
-    constexpr int C = KS * 16, CP = C + 8, MP = 128 + 8, TP = 128;
+template <typename T, int KS, int DT, int NW, bool WQL, bool MBL>
+__global__ __launch_bounds__(NW * 64, (KS <= 8 ? 2 : 1)) void la_out_kernel(dig_la_out_args a, int iters) {
+    constexpr int C = KS * 16, CP = C + 8, MP = 128 + 8, TP = NW * 32, NT = NW * 64;
     constexpr int QV = C >= 32 ? 4 : C / 8;  // valid 8-row groups of an output tile (C = 16: 2; otherwise C % 32 == 0)
-    constexpr bool PFX = KS <= 4;  // prefetch the next sub-tile's rows into registers
     constexpr int NV = (32 * (C / 8) + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* xs = reinterpret_cast<T*>(smem);                       // [TP][CP]
     float* bg = reinterpret_cast<float*>(xs + TP * CP);       // bias[DT*32] | g2[DT*32]
-    T* wqs = reinterpret_cast<T*>(bg + 2 * DT * 32);          // [128][CP]            (WLDS)
-    T* mbs = wqs + 128 * CP;                                  // [DT*32][MP] permuted (WLDS)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hf = lane >> 5;
+    T* wqs = reinterpret_cast<T*>(bg + 2 * DT * 32);          // [128][CP]            (WQL)
+    T* mbs = wqs + (WQL ? 128 * CP : 0);                      // [DT*32][MP] permuted (MBL)
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
     const T* x = (const T*)a.x + (size_t)b * a.n * C;
     T* out = (T*)a.out + (size_t)b * a.n * C;
     const T* Mb = (const T*)a.mb + (size_t)b * a.dim * 128;
-    for (int i = tid; i < DT * 32; i += 256) {
+    for (int i = tid; i < DT * 32; i += NT) {
         bg[i] = i < C ? a.bias[i] : 0.f;
         bg[DT * 32 + i] = i < C ? a.g2[i] : 0.f;
     }
-    if constexpr (WLDS) {
-        for (int i = tid; i < 128 * (C / 8); i += 256) {
+    if constexpr (WQL) {
+        for (int i = tid; i < 128 * (C / 8); i += NT) {
             const int row = i / (C / 8), v = i - row * (C / 8);
             Frag<T> f;
             frag_load<T>(f, (const T*)a.wq + (size_t)row * C + v * 8);
             frag_store<T>(f, wqs + row * CP + v * 8);
         }
-        for (int i = tid; i < DT * 32 * 32; i += 256) {
+    }
+    if constexpr (MBL) {
+        for (int i = tid; i < DT * 32 * 32; i += NT) {
             const int row = i >> 5, pc = i & 31, g = pc >> 2, q = pc & 3;
             const int nq = (q == 1) ? 2 : (q == 2) ? 1 : q;  // [0-3 | 8-11 | 4-7 | 12-15]: lane half hf reads 8 contiguous
             if (row < C) copy4<T>(mbs + row * MP + g * 16 + nq * 4, Mb + (size_t)row * 128 + pc * 4);
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256, (KS <= 8 ? 2 : 1)) void la_out_kernel(dig_la_o
     __syncthreads();
     T* xw = xs + wave * 32 * CP;
     const int nsub = a.n / 32;
-    const int sub0 = blockIdx.x * iters * 4 + wave;  // this wave's sub-tiles: sub0, sub0 + 4, ...
+    const int sub0 = blockIdx.x * iters * NW + wave;  // this wave's sub-tiles: sub0, sub0 + NW, ...
     Frag<T> pre[NV];
     auto gload = [&](int sub) {
 #pragma unroll
@@ -275,15 +277,16 @@ __global__ __launch_bounds__(256, (KS <= 8 ? 2 : 1)) void la_out_kernel(dig_la_o
             if (idx < 32 * (C / 8)) frag_store<T>(pre[i], xw + row * CP + v * 8);
         }
     };
+    constexpr bool PFX = sizeof(T) == 2 || KS <= 4;  // next sub-tile's rows wait in registers under this one's MFMAs
     if (PFX && sub0 < nsub) gload(sub0);
     for (int it = 0; it < iters; it++) {
-        const int sub = sub0 + it * 4;
+        const int sub = sub0 + it * NW;
         if (sub >= nsub) break;
         if (!PFX) gload(sub);
         __builtin_amdgcn_wave_barrier();
         lstore();
         __builtin_amdgcn_wave_barrier();
-        if (PFX && it + 1 < iters && sub + 4 < nsub) gload(sub + 4);
+        if (PFX && it + 1 < iters && sub + NW < nsub) gload(sub + NW);
         // ---- q[n'][p] = Wq'[n'] . x[p] per head (M tile = head, pixel = column), softmax over d, * scale -> B fragments
         Frag<T> qf[4][2];
         float c2 = 0.f;
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(256, (KS <= 8 ? 2 : 1)) void la_out_kernel(dig_la_o
                         ssq += xv * xv;
                     }
                 }
-                if constexpr (WLDS) frag_load<T>(fa, wqs + (hh * 32 + r) * CP + ks * 16 + hf * 8);
+                if constexpr (WQL) frag_load<T>(fa, wqs + (hh * 32 + r) * CP + ks * 16 + hf * 8);
                 else frag_load<T>(fa, (const T*)a.wq + (size_t)(hh * 32 + r) * C + ks * 16 + hf * 8);
                 mma16<T>(aq, fa, fb);
             }
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(256, (KS <= 8 ? 2 : 1)) void la_out_kernel(dig_la_o
 #pragma unroll
                 for (int s = 0; s < 2; s++) {
                     Frag<T> fa;
-                    if constexpr (WLDS) {
+                    if constexpr (MBL) {
                         frag_load<T>(fa, mbs + (ct * 32 + r) * MP + hh * 32 + 16 * s + 8 * hf);
                     } else {
                         const T* mp = Mb + (size_t)(ct * 32 + r) * 128 + hh * 32 + 16 * s + 4 * hf;  // j<4 at +0..3, j>=4 at +8..11 (acc_k)
@@ -389,20 +392,30 @@ __global__ __launch_bounds__(256, (KS <= 8 ? 2 : 1)) void la_out_kernel(dig_la_o
 template <typename T, int KS> int launch_kvctx(const dig_la_kvctx_args* a, hipStream_t st) {
     constexpr int C = KS * 16;
     const size_t lds = (size_t)64 * (C + 8) * sizeof(T);
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)la_kv_ctx_kernel<T, KS, (KS <= 4)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((la_kv_ctx_kernel<T, KS, (KS <= 4)>), dim3(a->splits, a->B), dim3(256), lds, st, *a);
+    constexpr bool WREG = sizeof(T) == 2 || KS <= 4;  // k/v weight fragments live in registers (fp32 fragments are twice as large)
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)la_kv_ctx_kernel<T, KS, WREG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((la_kv_ctx_kernel<T, KS, WREG>), dim3(a->splits, a->B), dim3(256), lds, st, *a);
     return 0;
 }
 template <typename T, int KS> int launch_out(const dig_la_out_args* a, hipStream_t st) {
     constexpr int C = KS * 16, DT = (C + 31) / 32;
-    constexpr bool WLDS = KS <= 4;
-    size_t lds = (size_t)128 * (C + 8) * sizeof(T) + 2 * DT * 32 * sizeof(float);
-    if (WLDS) lds += ((size_t)128 * (C + 8) + (size_t)DT * 32 * 136) * sizeof(T);
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)la_out_kernel<T, KS, DT, WLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int tiles = (a->n + 127) / 128;  // 128-pixel tiles per image
-    int iters = (int)(((long long)tiles * a->B) / 2048);
+    // LDS residency (bf16): C <= 64: Wq' and M_b, 4 waves, two blocks per CU; C = 128: both, 8 waves, one block per CU (140 KB);
+    // C = 256: M_b only (138 KB with the 4 waves' pixel rows), Wq' from L2.  fp32 storage keeps both in L2 above C = 64.
+    constexpr bool BF = sizeof(T) == 2;
+    constexpr bool WQL = KS <= 4 || (BF && KS == 8), MBL = KS <= 4 || (BF && KS >= 8);
+    constexpr int NW = (BF && KS == 8) ? 8 : 4;
+    size_t lds = (size_t)NW * 32 * (C + 8) * sizeof(T) + 2 * DT * 32 * sizeof(float);
+    if (WQL) lds += (size_t)128 * (C + 8) * sizeof(T);
+    if (MBL) lds += (size_t)DT * 32 * 136 * sizeof(T);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)la_out_kernel<T, KS, DT, NW, WQL, MBL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "la_out: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
+    }
+    const int tiles = (a->n + NW * 32 - 1) / (NW * 32);  // pixel tiles (one sub-tile per wave) per image
+    // sub-tiles per wave: the blocks that stage 70-100 KB of weights (one per CU) get as many as still leave a block per CU
+    int iters = (int)(((long long)tiles * a->B) / ((BF && KS >= 8) ? 256 : 2048));
     iters = iters < 1 ? 1 : (iters > 8 ? 8 : iters);
-    hipLaunchKernelGGL((la_out_kernel<T, KS, DT, WLDS>), dim3((unsigned)((tiles + iters - 1) / iters), a->B), dim3(256), lds, st, *a, iters);
+    hipLaunchKernelGGL((la_out_kernel<T, KS, DT, NW, WQL, MBL>), dim3((unsigned)((tiles + iters - 1) / iters), a->B), dim3(NW * 64), lds, st, *a, iters);
     return 0;
 }
 
