@@ -77,6 +77,39 @@ def test_conv3x3_concat_up2_prologue(dt):
     assert (nchw(y) - ref).abs().max() <= tol(dt, ref) * (1 if dt == torch.float32 else 2)
 
 
+@pytest.mark.parametrize("cfg", [(64, 64, 64, 40, 36), (128, 0, 64, 33, 70), (128, 0, 64, 16, 32), (64, 32, 128, 34, 20), (256, 0, 64, 64, 64)])
+def test_conv3x3_double_buffered_variants(cfg):
+    """The double-buffered bf16 kernel (Cout = 128) and the generic one (Cout = 64) on wide inputs: concat, nearest-x2 addressing,
+    GroupNorm-apply + SiLU prologue and the GroupNorm partials, on ragged tiles, against F.conv2d in fp32."""
+    C0, C1, Co, H, W = cfg
+    dt, B = torch.bfloat16, 2
+    x0 = q(rnd("bx0", (B, C0, H, W)), dt)
+    x1 = q(rnd("bx1", (B, C1, H, W)), dt) if C1 else None
+    w, b = q(rnd("bw", (Co, C0 + C1, 3, 3), (3.0 / (9 * (C0 + C1))) ** 0.5), dt), rnd("bb", (Co,), 0.1)
+    xin = torch.cat([x0, x1], 1) if C1 else x0
+    ref = F.conv2d(xin, w, b, padding=1)
+    cw = ops.ConvWeight(w.to(DEV), b.to(DEV), dt, C1=C1)
+    y, st = ops.conv3x3(nhwc(x0, dt), cw, x1=nhwc(x1, dt) if C1 else None)
+    assert (nchw(y) - ref).abs().max() <= tol(dt, ref)
+    st = st.cpu().double().sum(2)
+    g = ref.reshape(B, 8, -1).double()
+    assert torch.allclose(st[..., 0], g.sum(-1), rtol=1e-3, atol=1e-2 * g.shape[-1] ** 0.5)
+    assert torch.allclose(st[..., 1], (g * g).sum(-1), rtol=2e-2)
+    if C1 == 0:
+        # nearest x2 upsample addressing (Upsample, ddp.py:90-94)
+        xs = x0[:, :, : H // 2, : W // 2].contiguous()
+        H2, W2 = 2 * (H // 2), 2 * (W // 2)
+        ref = F.conv2d(F.interpolate(xs, scale_factor=2, mode="nearest"), w, b, padding=1)
+        y, _ = ops.conv3x3(nhwc(xs, dt), cw, up2=True, want_stats=False)
+        assert tuple(y.shape) == (B, H2, W2, Co) and (nchw(y) - ref).abs().max() <= tol(dt, ref)
+        # GroupNorm-apply + SiLU prologue
+        aff = torch.stack([1.0 + 0.3 * rnd("ba", (B, C0)), 0.2 * rnd("bbb", (B, C0))], -1)
+        xp = F.silu(x0 * aff[..., 0][:, :, None, None] + aff[..., 1][:, :, None, None])
+        ref = F.conv2d(q(xp, dt), w, b, padding=1)
+        y, _ = ops.conv3x3(nhwc(x0, dt), cw, aff=aff.to(DEV).contiguous())
+        assert (nchw(y) - ref).abs().max() <= 2 * tol(dt, ref)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("mnk", [(300, 200, 64), (128, 64, 32), (37, 3, 64), (5, 520, 256), (1000, 72, 136)])
 def test_gemm_epilogues(dt, mnk):

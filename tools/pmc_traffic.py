@@ -20,11 +20,16 @@ CLASSES = [
     ("conv3x3_bn32", r"conv3x3_kernelIDF16bLi32"),
     ("pw_res_k128_n64", r"pw_res_kernel<8"),
     ("pw_res_k192_n128", r"pw_res_kernel<12"),
-    ("gemm_bn128", r"gemm_nt_kernelIDF16bLi128"),
-    ("gemm_bn64", r"gemm_nt_kernelIDF16bLi64"),
+    ("gemm_bn128", r"gemm_nt_dma_kernelILi128|gemm_nt_kernelIDF16bLi128"),
+    ("gemm_bn64", r"gemm_nt_dma_kernelILi64|gemm_nt_kernelIDF16bLi64"),
+    ("final_conv", r"conv1x1_k64_nchw_kernel"),
     ("gn_silu_add", r"gn_silu_add"),
     ("la_kv_ctx_c64", r"la_kv_ctx_kernelIDF16bLi4"),
     ("la_out_c64", r"la_out_kernelIDF16bLi4"),
+    ("la_kv_ctx_c128", r"la_kv_ctx_kernelIDF16bLi8"),
+    ("la_out_c128", r"la_out_kernelIDF16bLi8"),
+    ("la_kv_ctx_c256", r"la_kv_ctx_kernelIDF16bLi16"),
+    ("la_out_c256", r"la_out_kernelIDF16bLi16"),
     ("stem", r"stem_kernel"),
     ("flash_attn", r"flash_attn_kernel"),
 ]
