@@ -188,6 +188,29 @@ def test_final_conv_stream(N):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 37, 50, 64), (1, 16, 32, 64), (3, 48, 70, 64), (2, 20, 24, 16)])
+def test_qsample_stem(dt, cfg):
+    """normalise + q_sample + init_conv 7x7 (ddp.py:82-83, 853-860, 296): x_t exact, conv against F.conv2d of the storage-rounded
+    x_t; ragged tiles, per-image timesteps.  Cout = 64 in bf16 is the im2col-free kernel, everything else the panel kernel."""
+    B, H, W, Co = cfg
+    img, nz = rnd("simg", (B, 3, H, W)), rnd("snz", (B, 3, H, W), 2.0)
+    w, b = q(rnd("sw", (Co, 3, 7, 7), 0.15), dt), rnd("sb", (Co,), 0.1)
+    t = torch.tensor([100, 0, 999][:B])
+    ca, cs = 0.5 + 0.5 * rnd("sca", (1000,)).abs(), rnd("scs", (1000,)).abs()
+    ps, sh = [2.0, 1.5, 0.5], [-1.0, 0.25, 0.0]
+    x0 = img * torch.tensor(ps)[None, :, None, None] + torch.tensor(sh)[None, :, None, None]
+    x_t_ref = ca[t][:, None, None, None] * x0 + cs[t][:, None, None, None] * nz
+    ref = F.conv2d(q(x_t_ref, dt), w, b, padding=3)
+    wp = F.pad(w.permute(0, 2, 3, 1).reshape(Co, 147), (0, 13)).contiguous().to(device=DEV, dtype=dt)
+    x_t = torch.empty(B, 3, H, W, device=DEV)
+    out = torch.empty(B, H, W, Co, dtype=dt, device=DEV)
+    call("qsample_stem", img=img.to(DEV), noise=nz.to(DEV), t=t.to(DEV), sqrt_ac=ca.to(DEV), sqrt_1mac=cs.to(DEV), w=wp, bias=b.to(DEV),
+         x_t=x_t, out=out, pre_scale=ps, pre_shift=sh, B=B, H=H, W=W, Cout=Co, dtype=dtype_code(dt))
+    assert (x_t.cpu() - x_t_ref).abs().max() <= 1e-6 * max(1.0, float(x_t_ref.abs().max()))
+    assert (nchw(out) - ref).abs().max() <= tol(dt, ref)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_gn_finalize_and_apply(dt):
     B, C, H, W = 2, 32, 20, 24
     x = q(rnd("x", (B, C, H, W)) * 2 + 0.5, dt)
