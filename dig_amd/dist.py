@@ -44,3 +44,41 @@ def run_sharded(fn, *batched_inputs, group=None):
     outs = [outs] if single else list(outs)
     res = [all_gather_batch(o, n, group) for o in outs]
     return res[0] if single else res
+
+
+class PipelinedGather:
+    """The all-gather of step i overlapped with the compute of step i+1: two output buffers, the collective is issued
+    asynchronously (RCCL runs it on its own stream, behind the producing kernels of the current stream) and waited for
+    one step later - a stream-level wait, the host never blocks.  `drain()` before reading the last result or stopping
+    a timer.  With one rank it is the identity."""
+
+    def __init__(self, shape, dtype, device, group=None, force=False):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.collective = self.world > 1 or (force and dist.is_initialized())  # force: run the collective even with one rank (rehearsal)
+        self.bufs = [torch.empty((self.world * shape[0],) + tuple(shape[1:]), dtype=dtype, device=device) for _ in range(2)] if self.collective else None
+        self.pending = None  # (work, output buffer, input kept alive)
+        self.count = 0
+
+    def submit(self, local):
+        """Queue the gather of `local` ([b, ...], equal b on every rank); returns the PREVIOUS step's gathered tensor (or None)."""
+        if not self.collective:
+            prev, self.pending = (self.pending[1] if self.pending else None), (None, local, None)
+            return prev
+        prev = self.drain()
+        out = self.bufs[self.count & 1]
+        self.count += 1
+        local = local.contiguous()
+        work = dist.all_gather_into_tensor(out, local, group=self.group, async_op=True)
+        self.pending = (work, out, local)
+        return prev
+
+    def drain(self):
+        """Make the current stream wait for the outstanding gather; returns its output (or None)."""
+        if self.pending is None:
+            return None
+        work, out, _ = self.pending
+        self.pending = None
+        if work is not None:
+            work.wait()
+        return out

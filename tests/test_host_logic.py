@@ -93,6 +93,18 @@ ra, rb = fn(x)
 assert torch.equal(a, ra) and torch.equal(b, rb), (rank, a.shape)
 lo, hi = dd.shard_bounds(n, world, rank)
 assert hi - lo in (n // world, n // world + 1)
+# pipelined gather (bench.py's N > 1 path): step i's collective is waited for at step i+1
+pg = dd.PipelinedGather((3, 4), torch.float32, "cpu")
+got = []
+for i in range(5):
+    prev = pg.submit(torch.full((3, 4), float(10 * i + rank)))
+    if prev is not None:
+        got.append(prev.clone())
+got.append(pg.drain().clone())
+assert pg.drain() is None and len(got) == 5
+for i, g in enumerate(got):
+    want = torch.cat([torch.full((3, 4), float(10 * i + r)) for r in range(world)])
+    assert torch.equal(g, want), (rank, i)
 dist.destroy_process_group()
 print("ok", rank)
 """
