@@ -157,6 +157,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_db_kernel(DbParams p) {
         for (int tap = 0; tap < 9; tap++) {
             const int ky = tap / 3, kx = tap - ky * 3;
             Frag<bf16> fa[2], fb[4];
+#ifdef DB_NO_FRAG  // ablation build: no fragment reads (the MFMAs run on whatever the registers hold)
+#pragma unroll
+            for (int mr = 0; mr < 2; mr++) asm volatile("" : "=v"(fa[mr].v));
+#pragma unroll
+            for (int nr = 0; nr < 4; nr++) asm volatile("" : "=v"(fb[nr].v));
+#else
 #pragma unroll
             for (int mr = 0; mr < 2; mr++) {
                 const int py = pg * 4 + mr * 2 + (r >> 4), px = r & 15;
@@ -165,10 +171,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_db_kernel(DbParams p) {
 #pragma unroll
             for (int nr = 0; nr < 4; nr++)
                 fb[nr].v = *reinterpret_cast<const bf16x8*>(wl + (tap * BN + nr * 32 + r) * 32 + ((hf ^ bsw) << 4));
+#endif
+#ifdef DB_NO_MFMA  // ablation build: fragment reads only
+#pragma unroll
+            for (int mr = 0; mr < 2; mr++) asm volatile("" ::"v"(fa[mr].v));
+#pragma unroll
+            for (int nr = 0; nr < 4; nr++) asm volatile("" ::"v"(fb[nr].v));
+#else
 #pragma unroll
             for (int mr = 0; mr < 2; mr++)
 #pragma unroll
                 for (int nr = 0; nr < 4; nr++) mma16<bf16>(acc[mr][nr], fa[mr], fb[nr]);
+#endif
             if (tap == DB_TAP_ISSUE && more) {  // next chunk's loads go out once the MFMA pipe has work queued behind the barrier
                 wload(ci + 1, nxt);
                 gload(ci + 1);
