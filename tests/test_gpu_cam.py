@@ -95,3 +95,22 @@ def test_guidance_loop_vs_reference_golden(golden, dt, tol):
     ref = T(g["img_diff"])
     err = float((img_diff.cpu() - ref).abs().max())
     assert err <= (tol if tol else 2e-2 * max(1.0, float(ref.abs().max()))), err
+
+
+@pytest.mark.parametrize("scale", [0.5, 1.5, 2.0])
+def test_cam_multiscale_flip_c80_vs_oracle(scale):
+    """BASELINE.json configs[4]: 80 classes, the scales of VOC12DatasetMS (voc12/data.py:794-809) with h-flip TTA.  The
+    reference defines only the multi-scale inputs, so parity is pinned per scale: normalised CAMs against the CPU oracle
+    (1e-4) and the uint8 argmax label map bit-exact against the oracle's numpy argmax of the device CAMs."""
+    C = 80
+    S = int(round(224 * scale / 16)) * 16
+    m = make_mct(C)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    img = synth.synth_imagenet_images(1, S, S, seed=31)
+    label = synth.synth_labels(1, C, seed=9)
+    ref = O.infer_multi_cam(sd, img, label, 12)
+    got = cam.infer_multi_cam(m, img.to(DEV), label.to(DEV), 12)
+    assert float((got.cpu() - ref).abs().max()) <= 1e-4
+    lab = cam.cam_labels(got, label.to(DEV), 0.45)[0].cpu().numpy()
+    assert lab.dtype == np.uint8 and lab.shape == (S, S)
+    assert np.array_equal(lab, O.cam_argmax_labels(cam.cam_dict(got[0], label[0]), 0.45, C + 1))
