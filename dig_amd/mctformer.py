@@ -42,9 +42,37 @@ class _PatchEmbed(_Holder):
         self.proj = nn.Conv2d(in_chans, dim, kernel_size=patch, stride=patch)
 
 
+class _ResBlockYsh(_Holder):
+    """Parameter holder with the reference's names (resnet101.py:31-38,195-207), groups = 1."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.convbnrelu1 = nn.Sequential(nn.Conv2d(cin, cout, 3, padding=1, bias=False), nn.GroupNorm(1, cout), nn.ReLU())
+        self.convbn2 = nn.Sequential(nn.Conv2d(cout, cout, 3, padding=1, bias=False), nn.GroupNorm(1, cout))
+        self.branch = nn.Conv2d(cin, cout, 1, bias=False)
+
+
+class _LFCA(_Holder):
+    """Parameter holder for LFCA(D, D_f, C) (mctformer.py:56-93); the forward is dig_amd/cam.py:lfca_forward."""
+
+    def __init__(self, D, Df):
+        super().__init__()
+        self.diff_init = _ResBlockYsh(Df * 5, Df)
+        self.norm_k, self.norm_v = nn.LayerNorm(D, eps=1e-6), nn.LayerNorm(Df, eps=1e-6)
+        self.norm_p1, self.norm_c1 = nn.GroupNorm(1, Df, eps=1e-6), nn.LayerNorm(D, eps=1e-6)
+        self.query = nn.Linear(D, D)
+        self.key = nn.Conv2d(Df, D, 1)
+        self.value = nn.Conv2d(Df, Df, 3, padding=1)
+        self.mlp_c0 = nn.Linear(Df, D)
+        self.mlp_p0 = nn.Conv2d(Df, Df, 3, padding=1)
+        self.mlp_c1 = nn.Sequential(nn.Linear(D, D * 4), nn.GELU(), nn.Linear(D * 4, D))
+        self.mlp_p1 = nn.Sequential(nn.Conv2d(Df, Df * 4, 1), nn.GELU(), nn.Conv2d(Df * 4, Df, 1))
+
+
 class MCTformerV2_DiG(nn.Module):
-    """`lfca=False` omits the LFCA0/LFCA1/diff_head_p parameters (191 M, training-only consumer of the guidance
-    maps); load reference checkpoints with strict=False in that case."""
+    """`lfca=False` (default) omits the LFCA0/LFCA1/diff_head_p parameters (191 M; the consumer of the guidance maps,
+    used by the training step - load reference checkpoints with strict=False in that case); `lfca=True` creates them
+    under the reference's names and enables forward(x, feat_diff=[5 x [B,1024,h,w]]) in eval mode."""
 
     def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=20, embed_dim=384, depth=12, num_heads=6,
                  mlp_ratio=4., lfca=False, **_ignored):
@@ -57,15 +85,24 @@ class MCTformerV2_DiG(nn.Module):
         self.blocks = nn.ModuleList([_Block(embed_dim, mlp_ratio) for _ in range(depth)])
         self.norm = nn.LayerNorm(embed_dim, eps=1e-6)  # present in the checkpoint, unused by the DiG forward
         self.head = nn.Conv2d(embed_dim, num_classes, kernel_size=3, stride=1, padding=1)
+        self.D_f, self.D = 512 + 512, 384  # mctformer.py:183-184
         if lfca:
-            raise NotImplementedError("LFCA consumer is outside round-1 scope (SURVEY.md 8f-1)")
+            assert embed_dim == self.D, "LFCA hard-codes D = 384 (mctformer.py:138-146)"
+            self.LFCA0, self.LFCA1 = _LFCA(self.D, self.D_f), _LFCA(self.D, self.D_f)
+            # the reference hard-codes 20 output maps here whatever num_classes is (mctformer.py:189)
+            self.diff_head_p = nn.Sequential(nn.Conv2d(self.D_f, self.D_f, 3, 1, 1), nn.ReLU(inplace=True), nn.Conv2d(self.D_f, 20, 1, 1, 0))
+        self.has_lfca = bool(lfca)
         self._packed = None
+        self._packed_lfca = None
 
     def forward(self, x, feat_diff=None, return_att=False, n_layers=12, detach=True):
         from . import cam
         if feat_diff is not None:
-            raise NotImplementedError("the LFCA branch (training-only) is outside the guidance/CAM hot path")
-        outs = cam.mctformer_forward(self, x, n_layers)
+            if not self.has_lfca:
+                raise RuntimeError("this model was built with lfca=False: no LFCA0/LFCA1/diff_head_p parameters")
+            if self.training:
+                raise NotImplementedError("the LFCA branch is forward-only here (DropPath 0.1 is a training feature); call .eval()")
+        outs = cam.mctformer_forward(self, x, n_layers, feat_diff=feat_diff)
         return outs["rcams"] if return_att else outs
 
 

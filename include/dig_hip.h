@@ -398,6 +398,41 @@ typedef struct {
 } dig_cam_argmax_args;
 int dig_cam_argmax(const dig_cam_argmax_args* a, void* stream);
 
+/* ---- LFCA consumer of the guidance maps (networks/mctformer.py:56-166, networks/resnet101.py:195-222) ----
+ * out = post(pre(x_scale * (a[b][c] * x + b[b][c])) + res_scale * res) on NHWC [B][HW][C] (C % 8 == 0).
+ * aff [B][C][2] fp32 or NULL (identity); res NULL or same shape as x.  pre_act / post_act: 0 none, 1 SiLU, 2 ReLU, 3 GELU(erf).
+ * Covers GroupNorm-apply + ReLU (ConvGnReLU, resnet101.py:35-38), relu(GroupNorm(y) + branch) (resnet101.py:214-222), the
+ * plain GroupNorm-apply of norm_p1 (mctformer.py:164) and the LFCA0/LFCA1 average (mctformer.py:286-287). */
+typedef struct {
+    const void* x;
+    const float* aff;
+    const void* res;
+    void* out;
+    int B, HW, C, pre_act, post_act, dtype;
+    float x_scale, res_scale;
+} dig_affine_act_add_args;
+int dig_affine_act_add(const dig_affine_act_add_args* a, void* stream);
+
+/* GroupNorm statistics of an NHWC tensor that is not a conv3x3 output (norm_p1 on x_p, mctformer.py:163-164):
+ * stats[b][g][tile][2] = (sum, sum of squares) over pixel slab `tile` (HW split into `tiles` contiguous slabs), the layout
+ * dig_gn_finalize reads.  (C / groups) % 8 == 0, groups <= 256.  Fixed summation order: deterministic. */
+typedef struct {
+    const void* x;
+    float* stats;
+    int B, HW, C, groups, tiles, dtype;
+} dig_gn_stats_args;
+int dig_gn_stats(const dig_gn_stats_args* a, void* stream);
+
+/* F.interpolate(x, size=(ho, wo), mode='bilinear', align_corners=False) on NHWC [B][hi][wi][C] -> [B][ho][wo][C],
+ * optionally + res (x_p = kv + interpolate(o_p), mctformer.py:161-163). */
+typedef struct {
+    const void* in;
+    const void* res;
+    void* out;
+    int B, hi, wi, ho, wo, C, dtype;
+} dig_bilinear_resize_args;
+int dig_bilinear_resize(const dig_bilinear_resize_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -300,8 +300,9 @@ def vit_pos_embed(sd, num_classes, H, W, patch=16):
     return torch.cat([pe[:, :num_classes], pp], dim=1)
 
 
-def vit_block(w, x, heads):
-    """Block + Attention + Mlp, vision_transformer.py:54-103,177-196.  Returns (x, probs)."""
+def vit_block(w, x, heads, want_q=False):
+    """Block + Attention + Mlp, vision_transformer.py:54-103,177-196.  Returns (x, probs) or, with want_q,
+    (x, probs, q) where q is the un-scaled query [B, heads, N, D/heads] that Attention.forward hands back (:96-103)."""
     B, N, D = x.shape
     y = F.layer_norm(x, (D,), w["norm1.weight"], w["norm1.bias"], eps=1e-6)
     qkv = F.linear(y, w["attn.qkv.weight"], w["attn.qkv.bias"]).reshape(B, N, 3, heads, D // heads)
@@ -311,7 +312,7 @@ def vit_block(w, x, heads):
     x = x + F.linear(o, w["attn.proj.weight"], w["attn.proj.bias"])
     y = F.layer_norm(x, (D,), w["norm2.weight"], w["norm2.bias"], eps=1e-6)
     y = F.linear(F.gelu(F.linear(y, w["mlp.fc1.weight"], w["mlp.fc1.bias"])), w["mlp.fc2.weight"], w["mlp.fc2.bias"])
-    return x + y, p
+    return (x + y, p, q) if want_q else (x + y, p)
 
 
 def mctformer_cam(sd, img, n_layers=12, heads=6, patch=16, collect=None):
@@ -328,11 +329,16 @@ def mctformer_cam(sd, img, n_layers=12, heads=6, patch=16, collect=None):
     while f"blocks.{depth}.norm1.weight" in sd:
         depth += 1
     probs = []
+    qs = []
     for i in range(depth):
-        x, p = vit_block(_sub(sd, f"blocks.{i}."), x, heads)
+        x, p, q = vit_block(_sub(sd, f"blocks.{i}."), x, heads, want_q=True)
         probs.append(p.mean(dim=1))  # head mean, mctformer.py:303
+        qs.append(q)
     if collect is not None:
         collect["tokens"] = x
+        # the LFCA queries, mctformer.py:279-281: q of the last / second-to-last block as [B, C+N, D]
+        collect["query0"] = qs[-1].permute(0, 2, 1, 3).reshape(B, -1, D)
+        collect["query1"] = qs[-2].permute(0, 2, 1, 3).reshape(B, -1, D)
     # no final self.norm in the DiG subclass (mctformer.py:242-250)
     xp = x[:, C:].reshape(B, hp, wp, D).permute(0, 3, 1, 2).contiguous()
     head = F.conv2d(xp, sd["head.weight"], sd["head.bias"], padding=1)
@@ -345,6 +351,70 @@ def mctformer_cam(sd, img, n_layers=12, heads=6, patch=16, collect=None):
     if collect is not None:
         collect.update(mtatt=mtatt, patch_attn=patch_attn, fmap=fmap, head=head)
     return rcams
+
+
+def _gn1(x, w, b, eps):
+    return F.group_norm(x, 1, w, b, eps)
+
+
+def res_block_ysh(w, x):
+    """ResBlock_ysh(in, out, groups=1), resnet101.py:31-38,195-222: conv3x3(no bias) - GroupNorm(1) - ReLU,
+    conv3x3(no bias) - GroupNorm(1), + 1x1 branch (no bias), ReLU.  (`groups` is passed to both the conv and the
+    GroupNorm; LFCA uses groups=1, mctformer.py:64-67.)"""
+    y = F.relu(_gn1(F.conv2d(x, w["convbnrelu1.0.weight"], None, padding=1), w["convbnrelu1.1.weight"], w["convbnrelu1.1.bias"], 1e-5))
+    y = _gn1(F.conv2d(y, w["convbn2.0.weight"], None, padding=1), w["convbn2.1.weight"], w["convbn2.1.bias"], 1e-5)
+    return F.relu(y + F.conv2d(x, w["branch.weight"]))
+
+
+def lfca(w, query_vit, feat_cat, C, heads=8):
+    """LFCA.forward in eval mode (DropPath = identity), mctformer.py:124-166.
+    query_vit [B, C+N, D]; feat_cat [B, 5*D_f, h, w] -> (x_c [B, C, D], x_p [B, D_f, h, w])."""
+    B, _, hd, wd = feat_cat.shape
+    D = query_vit.shape[-1]
+    N = query_vit.shape[1] - C
+    ht = wt = int(N ** 0.5)
+    kv = res_block_ysh(_sub(w, "diff_init."), feat_cat)
+    Df = kv.shape[1]
+    nk = lambda t: F.layer_norm(t, (D,), w["norm_k.weight"], w["norm_k.bias"], 1e-6)
+    q = nk(F.linear(query_vit, w["query.weight"], w["query.bias"]))
+    k = nk(F.conv2d(kv, w["key.weight"], w["key.bias"]).reshape(B, D, -1).permute(0, 2, 1))
+    v = F.layer_norm(F.conv2d(kv, w["value.weight"], w["value.bias"], padding=1).reshape(B, Df, -1).permute(0, 2, 1),
+                     (Df,), w["norm_v.weight"], w["norm_v.bias"], 1e-6)
+    q = q.reshape(B, -1, heads, D // heads).permute(0, 2, 1, 3)
+    k = k.reshape(B, -1, heads, D // heads).permute(0, 2, 1, 3)
+    v = v.reshape(B, -1, heads, Df // heads).permute(0, 2, 1, 3)
+    a = F.softmax(torch.matmul(q, k.transpose(-2, -1)) / ((384 // 8) ** 0.5), dim=-1)  # the reference hard-codes 384//8 (:146)
+    o = torch.matmul(a, v).transpose(1, 2).reshape(B, N + C, -1)
+    o_c = o[:, :C]
+    o_p = o[:, C:].permute(0, 2, 1).reshape(B, Df, ht, wt)
+    x_c = F.linear(o_c, w["mlp_c0.weight"], w["mlp_c0.bias"]) + query_vit[:, :C]
+    y = F.layer_norm(x_c, (D,), w["norm_c1.weight"], w["norm_c1.bias"], 1e-6)
+    x_c = F.linear(F.gelu(F.linear(y, w["mlp_c1.0.weight"], w["mlp_c1.0.bias"])), w["mlp_c1.2.weight"], w["mlp_c1.2.bias"]) + x_c
+    o_p = F.conv2d(o_p, w["mlp_p0.weight"], w["mlp_p0.bias"], padding=1)
+    o_p = F.interpolate(o_p, size=(hd, wd), mode="bilinear", align_corners=False)
+    x_p = kv + o_p
+    y = _gn1(x_p, w["norm_p1.weight"], w["norm_p1.bias"], 1e-6)
+    x_p = F.conv2d(F.gelu(F.conv2d(y, w["mlp_p1.0.weight"], w["mlp_p1.0.bias"])), w["mlp_p1.2.weight"], w["mlp_p1.2.bias"]) + x_p
+    return x_c, x_p
+
+
+def mctformer_lfca(sd, img, feat_diff, n_layers=12):
+    """MCTformerV2_DiG.forward(x, feat_diff=[5 x [B,1024,h,w]]) in eval mode: the extra dict entries of the LFCA
+    branch, mctformer.py:265-291,324-346.  Returns {rcams, cam_diff, diff_cls, diff_pcls}."""
+    col = {}
+    rcams = mctformer_cam(sd, img, n_layers, collect=col)
+    B = img.shape[0]
+    C = sd["cls_token"].shape[1]
+    hd, wd = feat_diff[0].shape[2:]
+    cat = torch.stack(feat_diff, dim=1).reshape(B, -1, hd, wd)  # timestep-major channel order (:275)
+    c0, p0 = lfca(_sub(sd, "LFCA0."), col["query0"], cat, C)
+    c1, p1 = lfca(_sub(sd, "LFCA1."), col["query1"], cat, C)
+    out_c, out_p = (c0 + c1) / 2, (p0 + p1) / 2
+    y = F.relu(F.conv2d(out_p, sd["diff_head_p.0.weight"], sd["diff_head_p.0.bias"], padding=1))
+    cam_diff = F.conv2d(y, sd["diff_head_p.2.weight"], sd["diff_head_p.2.bias"])
+    top = lambda t: torch.topk(t.reshape(B, cam_diff.shape[1], -1), dim=-1, k=3)[0].mean(-1)
+    return {"rcams": rcams, "cam_diff": F.relu(cam_diff), "diff_cls": out_c.mean(-1),
+            "diff_pcls": top(F.relu(cam_diff)) - top(F.relu(-cam_diff))}
 
 
 def max_norm(cam):

@@ -9,6 +9,7 @@ oracle/ref_import.py with off-path dependency stubs).  For every case it
   4. stores the reference outputs as small .npz fixtures (plain arrays, allow_pickle=False).
 
 Usage:  python oracle/gen_golden.py            (rewrites tests/golden/)
+        python oracle/gen_golden.py lfca       (only the LFCA cases; merges into MANIFEST.json)
 """
 import json
 import os
@@ -211,10 +212,35 @@ def case_cam(mct, name, C, H, W, B, thresholds=(0.35, 0.45)):
     save(name, **arrays)
 
 
+def case_lfca(mct, name, C, H, W, hd, wd):
+    """(f)-1: the LFCA consumer of the guidance maps, MCTformerV2_DiG.forward(x, feat_diff=...) in eval mode."""
+    m = mct.deit_small_MCTformerV2_DiG(num_classes=C).eval()
+    synth.fill_state_dict(m, seed=0, skip_prefixes=("norm.",))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    img = synth.synth_imagenet_images(1, H, W, seed=4400)
+    feat = [synth.normal("feat_diff", (1, 1024, hd, wd), seed=7 + j) * 1.5 for j in range(5)]
+    with torch.no_grad():
+        outs = m(img, feat_diff=feat)
+        o = O.mctformer_lfca(sd, img, feat)
+    d = {k: maxabs(outs[k], o[k]) for k in ("rcams", "cam_diff", "diff_cls", "diff_pcls")}
+    record(name, **d)
+    save(name, cam_diff=outs["cam_diff"], diff_cls=outs["diff_cls"], diff_pcls=outs["diff_pcls"], rcams=outs["rcams"])
+
+
 def main():
     assert ref_import.reference_available(), "reference not mounted - goldens can only be generated in the build container"
-    ddp = ref_import.load_ddp()
     mct = ref_import.load_mctformer()
+    if sys.argv[1:] == ["lfca"]:  # add / refresh only the LFCA cases, keeping the rest of the manifest
+        case_lfca(mct, "lfca224_c20", 20, 224, 224, 14, 14)
+        case_lfca(mct, "lfca224_c20_maps16", 20, 224, 224, 16, 16)
+        mp = os.path.join(GOLD, "MANIFEST.json")
+        with open(mp) as f:
+            man = json.load(f)
+        man["cases"].update(MANIFEST)
+        with open(mp, "w") as f:
+            json.dump(man, f, indent=1)
+        return
+    ddp = ref_import.load_ddp()
     case_schedule(ddp)
     case_ops(ddp)
     case_unet(ddp, "unet_tiny32", 16, 32, 32, 2, [3, 100], keep_inter=True)
@@ -224,6 +250,8 @@ def main():
     case_cam(mct, "cam224_c20", 20, 224, 224, 1)
     case_cam(mct, "cam160x208_c20", 20, 160, 208, 1)
     case_cam(mct, "cam224_c80", 80, 224, 224, 1)
+    case_lfca(mct, "lfca224_c20", 20, 224, 224, 14, 14)
+    case_lfca(mct, "lfca224_c20_maps16", 20, 224, 224, 16, 16)  # guidance maps from a 256x256 diffusion input: bilinear 14 -> 16
     with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
         json.dump({"generator": "oracle/gen_golden.py", "torch": torch.__version__,
                    "what": "max-abs |reference - oracle| per output, fp32 CPU", "cases": MANIFEST,

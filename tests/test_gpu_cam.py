@@ -114,3 +114,28 @@ def test_cam_multiscale_flip_c80_vs_oracle(scale):
     lab = cam.cam_labels(got, label.to(DEV), 0.45)[0].cpu().numpy()
     assert lab.dtype == np.uint8 and lab.shape == (S, S)
     assert np.array_equal(lab, O.cam_argmax_labels(cam.cam_dict(got[0], label[0]), 0.45, C + 1))
+
+
+@pytest.mark.parametrize("name,hd", [("lfca224_c20", 14), ("lfca224_c20_maps16", 16)])
+def test_lfca_consumer_vs_reference_golden(golden, name, hd):
+    """SURVEY 8f-1, the step right after the guidance maps: MCTformerV2_DiG.forward(x, feat_diff=[5 x [B,1024,h,w]]) in eval
+    mode (LFCA0/LFCA1 cross attention + diff_head_p, mctformer.py:56-166,265-291,324-346) on the HIP kernels, fp32, against the
+    reference's outputs.  The second case has 16x16 guidance maps for a 14x14 token grid (bilinear resize inside LFCA)."""
+    g = golden(name)
+    m = create_model("deit_small_MCTformerV2_DiG", pretrained=False, num_classes=20, lfca=True)
+    synth.fill_state_dict(m, seed=0, skip_prefixes=("norm.",))
+    m = m.to(DEV).eval()
+    img = synth.synth_imagenet_images(1, 224, 224, seed=4400).to(DEV)
+    feat = [(synth.normal("feat_diff", (1, 1024, hd, hd), seed=7 + j) * 1.5).to(DEV) for j in range(5)]
+    outs = m(img, feat_diff=feat)
+    assert set(outs) >= {"cls", "pcls", "cams", "fcams", "attn", "mtatt", "rcams", "feat", "cam_diff", "diff_cls", "diff_pcls"}
+    for k in ("rcams", "cam_diff", "diff_cls", "diff_pcls"):
+        ref = T(g[k])
+        err = float((outs[k].cpu() - ref).abs().max())
+        print(name, k, err, float(ref.abs().max()))
+        assert err <= 2e-4 * max(1.0, float(ref.abs().max())), (k, err)
+    # batch of 2 (the second image alone gives the same result: everything is per image)
+    img2 = torch.cat([synth.synth_imagenet_images(1, 224, 224, seed=11).to(DEV), img])
+    feat2 = [torch.cat([0.5 * f, f]) for f in feat]
+    o2 = m(img2, feat_diff=feat2)
+    assert float((o2["cam_diff"][1:] - outs["cam_diff"]).abs().max()) <= 1e-5

@@ -333,3 +333,34 @@ def test_pw_res_tail(shape):
     assert (y.float().cpu() - ref).abs().max() <= tol(dt, ref)
     y2 = ops.linear_rows(d(x0), d(w), bias=bias.to(DEV), x1=d(x1), gsrc=d(h2), gaff=aff.to(DEV), rows_per_img=H * W)
     assert (y.float() - y2.float()).abs().max().item() <= tol(dt, ref)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_lfca_helper_kernels(dt):
+    """dig_gn_stats + dig_gn_finalize + dig_affine_act_add (GroupNorm on a tensor that is not a conv output, with the
+    activation placements of resnet101.py:35-38,214-222) and dig_bilinear_resize (F.interpolate align_corners=False)."""
+    B, H, W, C = 2, 9, 7, 48
+    x = q(rnd("lx", (B, C, H, W), 2.0), dt)
+    res = q(rnd("lr", (B, C, H, W)), dt)
+    gamma, beta = 1.0 + 0.2 * rnd("lg", (C,)), 0.1 * rnd("lb", (C,))
+    xd, rd = nhwc(x, dt), nhwc(res, dt)
+    for groups, tiles in ((1, 5), (3, 1), (6, 63)):
+        st = torch.empty(B, groups, tiles, 2, dtype=torch.float32, device=DEV)
+        call("gn_stats", x=xd, stats=st, B=B, HW=H * W, C=C, groups=groups, tiles=tiles, dtype=dtype_code(dt))
+        aff = ops.gn_finalize(st, gamma.to(DEV), beta.to(DEV), H * W, eps=1e-6)
+        gn = F.group_norm(x, groups, gamma, beta, 1e-6)
+        for pre, post, fn in ((2, 0, lambda: F.relu(gn) + 0.5 * res), (0, 2, lambda: F.relu(gn + 0.5 * res)), (3, 1, lambda: F.silu(F.gelu(gn) + 0.5 * res))):
+            out = torch.empty_like(xd)
+            call("affine_act_add", x=xd, aff=aff, res=rd, out=out, B=B, HW=H * W, C=C, pre_act=pre, post_act=post, dtype=dtype_code(dt),
+                 x_scale=1.0, res_scale=0.5)
+            ref = fn()
+            assert (nchw(out) - ref).abs().max() <= tol(dt, ref) * (1 if dt == torch.float32 else 2), (groups, pre, post)
+    out = torch.empty_like(xd)
+    call("affine_act_add", x=xd, aff=None, res=rd, out=out, B=B, HW=H * W, C=C, pre_act=0, post_act=0, dtype=dtype_code(dt), x_scale=0.5, res_scale=0.5)
+    assert (nchw(out) - (x + res) / 2).abs().max() <= tol(dt, x)
+    for ho, wo in ((9, 7), (16, 16), (5, 11), (18, 3)):
+        out = torch.empty(B, ho, wo, C, dtype=dt, device=DEV)
+        rr = q(rnd("lrr", (B, C, ho, wo)), dt)
+        call("bilinear_resize", **{"in": xd}, res=nhwc(rr, dt), out=out, B=B, hi=H, wi=W, ho=ho, wo=wo, C=C, dtype=dtype_code(dt))
+        ref = F.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=False) + rr
+        assert (nchw(out) - ref).abs().max() <= (1e-5 if dt == torch.float32 else tol(dt, ref)), (ho, wo)

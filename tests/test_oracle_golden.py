@@ -124,3 +124,16 @@ def test_cam_nonsquare(golden):
 
 def test_cam_c80(golden):
     _check_cam(golden, "cam224_c80", 80, 224, 224)
+
+
+def test_lfca_consumer(golden):
+    """the LFCA branch (mctformer.py:56-166,265-291) - oracle restatement against the reference's outputs."""
+    g = golden("lfca224_c20")
+    m = create_model("deit_small_MCTformerV2_DiG", pretrained=False, num_classes=20, lfca=True)
+    synth.fill_state_dict(m, seed=0, skip_prefixes=("norm.",))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    img = synth.synth_imagenet_images(1, 224, 224, seed=4400)
+    feat = [synth.normal("feat_diff", (1, 1024, 14, 14), seed=7 + j) * 1.5 for j in range(5)]
+    o = O.mctformer_lfca(sd, img, feat)
+    for k in ("rcams", "cam_diff", "diff_cls", "diff_pcls"):
+        assert (o[k] - T(g[k])).abs().max() <= TOL, k
