@@ -50,3 +50,15 @@ def extract_guidance(diffusion, img, noises=None, t_list=T_LIST, sfi=100, batche
             img_diff = diffusion._axpby(x_t, v, tt, -1.0, post_scale=tuple(0.5 / s for s in IMAGENET_STD),
                                         post_shift=tuple((0.5 - m) / s for m, s in zip(IMAGENET_MEAN, IMAGENET_STD)))
     return [maps[j] for j in low], img_diff
+
+
+def update_forward(diffusion, net_trm, img, noises=None, n_layers=12):
+    """The forward computations of model_WSSS.update (models/model_ECCV24_DiG.py:286-322,396-404), inference mode:
+    guidance maps at t = 0..4 and the t = 100 reconstruction from the diffusion Unet, the MCTformer pass that consumes the
+    maps through LFCA0/LFCA1 (`net_trm(img, feat_diff_list)`), and the second MCTformer pass on the reconstruction
+    (`net_trm(img_diff)`).  The losses and the optimiser step that follow in the reference are outside this build.
+    Returns (outputs, outputs_diff, feat_diff_list, img_diff)."""
+    feat_diff_list, img_diff = extract_guidance(diffusion, img, noises)
+    outputs = net_trm(img, feat_diff=feat_diff_list, n_layers=n_layers)
+    outputs_diff = net_trm(img_diff, n_layers=n_layers)
+    return outputs, outputs_diff, feat_diff_list, img_diff

@@ -417,6 +417,15 @@ def mctformer_lfca(sd, img, feat_diff, n_layers=12):
             "diff_pcls": top(F.relu(cam_diff)) - top(F.relu(-cam_diff))}
 
 
+def update_forward(sd_diffusion, sd_mct, img, noises, n_layers=12):
+    """Forward part of model_WSSS.update, model.py:286-322 (guidance maps -> net_trm(img, feat_diff_list)) and
+    model.py:396-404 (net_trm(img_diff)), composed from the restated pieces; eval mode.
+    Returns (LFCA-branch dict, rcams of the img_diff pass, maps, img_diff)."""
+    maps, img_diff = guidance_maps(sd_diffusion, img, noises)
+    outs = mctformer_lfca(sd_mct, img, maps, n_layers)
+    return outs, mctformer_cam(sd_mct, img_diff, n_layers), maps, img_diff
+
+
 def max_norm(cam):
     """model.py:572-578 == mctformer.py:219-225."""
     N, C, H, W = cam.shape

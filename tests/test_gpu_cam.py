@@ -139,3 +139,28 @@ def test_lfca_consumer_vs_reference_golden(golden, name, hd):
     feat2 = [torch.cat([0.5 * f, f]) for f in feat]
     o2 = m(img2, feat_diff=feat2)
     assert float((o2["cam_diff"][1:] - outs["cam_diff"]).abs().max()) <= 1e-5
+
+
+def test_update_forward_pipeline_vs_oracle():
+    """model.py:286-322,396-404 end to end (fp32): six Unet passes -> five guidance maps + img_diff -> MCTformer with the LFCA
+    consumer -> MCTformer on the reconstruction, against the CPU oracle's composition of the same pieces."""
+    H = W = 64
+    u = Unet(dim=64, dim_mults=(1, 2, 4, 8), flash_attn=True)
+    synth.fill_state_dict(u, seed=0)
+    gd = GaussianDiffusion(u, image_size=H, timesteps=1000, sampling_timesteps=150).eval()
+    m = create_model("deit_small_MCTformerV2_DiG", pretrained=False, num_classes=20, lfca=True)
+    synth.fill_state_dict(m, seed=0, skip_prefixes=("norm.",))
+    m.eval()
+    sd_d = {k: v.detach().clone() for k, v in gd.state_dict().items()}
+    sd_m = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    img = synth.synth_imagenet_images(1, H, W, seed=21)
+    noises = [synth.synth_noise(1, H, W, seed=500 + j) for j in range(6)]
+    ro, rdiff, rmaps, rimg = O.update_forward(sd_d, sd_m, img, noises)
+    gd, m = gd.to(DEV), m.to(DEV)
+    u.set_compute_dtype(torch.float32)
+    outs, outs_diff, maps, img_diff = guidance.update_forward(gd, m, img.to(DEV), [n.to(DEV) for n in noises])
+    rel = lambda a, b: float((a.cpu() - b).abs().max()) / max(1.0, float(b.abs().max()))
+    assert max(rel(a, b) for a, b in zip(maps, rmaps)) <= 1e-3 and rel(img_diff, rimg) <= 1e-3
+    for k in ("rcams", "cam_diff", "diff_cls", "diff_pcls"):
+        assert rel(outs[k], ro[k]) <= 1e-3, (k, rel(outs[k], ro[k]))
+    assert rel(outs_diff["rcams"], rdiff) <= 1e-3
