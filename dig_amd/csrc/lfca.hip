@@ -178,3 +178,44 @@ extern "C" int dig_bilinear_resize(const dig_bilinear_resize_args* a, void* stre
     DIG_LAUNCH_CHECK("bilinear_resize");
     return DIG_OK;
 }
+
+// ---- mIoU bookkeeping of evaluation.py:72-88 on the device ---------------------------------------------------------------
+// counts[0][i] += #(predict == i and gt < 255)   (P)
+// counts[1][i] += #(gt == i and gt < 255)        (T)
+// counts[2][i] += #(gt == i and predict == gt and gt < 255)   (TP)
+// Integer counters: block-local LDS histogram, then one 64-bit atomic per non-empty bin (order-independent, exact).
+namespace {
+__global__ __launch_bounds__(256) void seg_hist_kernel(const unsigned char* __restrict__ predict, const unsigned char* __restrict__ gt,
+                                                       unsigned long long* __restrict__ counts, long long n, int num_cls) {
+    __shared__ unsigned int h[3 * 256];
+    for (int i = threadIdx.x; i < 3 * 256; i += 256) h[i] = 0u;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int p = predict[i], g = gt[i];
+        if (g < 255) {
+            if (p < num_cls) atomicAdd(&h[p], 1u);
+            if (g < num_cls) {
+                atomicAdd(&h[256 + g], 1u);
+                if (p == g) atomicAdd(&h[512 + g], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * 256; i += 256) {
+        const int k = i >> 8, c = i & 255;
+        if (c < num_cls && h[i] != 0u) atomicAdd(&counts[(size_t)k * num_cls + c], (unsigned long long)h[i]);
+    }
+}
+}  // namespace
+
+extern "C" int dig_seg_hist(const dig_seg_hist_args* a, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DIG_CHECK(a && a->predict && a->gt && a->counts, DIG_EINVAL, "seg_hist: null pointer");
+    DIG_CHECK(a->n > 0 && a->num_cls > 0 && a->num_cls <= 255, DIG_EINVAL, "seg_hist: bad shape (num_cls <= 255: 255 is the ignore label)");
+    long long blocks = (a->n + 256LL * 16 - 1) / (256LL * 16);  // 16 pixels per thread: each block's 2^32-safe LDS counters see <= 4096 pixels per pass of the grid
+    if (blocks > 2048) blocks = 2048;
+    DIG_CHECK(a->n / blocks < 4000000000LL, DIG_EINVAL, "seg_hist: too many pixels per call for the 32-bit block counters");
+    hipLaunchKernelGGL(seg_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a->predict, a->gt, a->counts, a->n, a->num_cls);
+    DIG_LAUNCH_CHECK("seg_hist");
+    return DIG_OK;
+}

@@ -433,6 +433,18 @@ typedef struct {
 } dig_bilinear_resize_args;
 int dig_bilinear_resize(const dig_bilinear_resize_args* a, void* stream);
 
+/* mIoU bookkeeping (evaluation.py:72-88): predict, gt uint8 [n] (255 in gt = rejected boundary pixel);
+ * counts uint64 [3][num_cls] are ADDED to: P (predict == i), T (gt == i), TP (gt == i and predict == gt), each over gt < 255.
+ * The caller zeroes counts once and calls this per image or per batch; integer atomics, exact. */
+typedef struct {
+    const unsigned char* predict;
+    const unsigned char* gt;
+    unsigned long long* counts;
+    long long n;
+    int num_cls;
+} dig_seg_hist_args;
+int dig_seg_hist(const dig_seg_hist_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

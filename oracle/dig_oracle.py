@@ -460,3 +460,39 @@ def cam_argmax_labels(cam_dict, threshold, num_cls=21):
         t[k + 1] = v
     t[0] = threshold
     return np.argmax(t, axis=0).astype(np.uint8)
+
+
+def seg_counts(predicts, gts, num_cls=21):
+    """evaluation.py:72-88 without the multiprocessing wrapper: P, T, TP per class as exact integers."""
+    P, T, TP = (np.zeros(num_cls, np.int64) for _ in range(3))
+    for predict, gt in zip(predicts, gts):
+        cal = gt < 255
+        mask = (predict == gt) * cal
+        for i in range(num_cls):
+            P[i] += np.sum((predict == i) * cal)
+            T[i] += np.sum((gt == i) * cal)
+            TP[i] += np.sum((gt == i) * mask)
+    return P, T, TP
+
+
+def seg_metrics(P, T, TP):
+    """evaluation.py:96-122: IoU per class (percent), mIoU (percent), mean precision / recall."""
+    iou = [TP[i] / (T[i] + P[i] - TP[i] + 1e-10) for i in range(len(P))]
+    prec = [TP[i] / (P[i] + 1e-10) for i in range(len(P))]
+    rec = [TP[i] / (T[i] + 1e-10) for i in range(len(P))]
+    return {"IoU": [v * 100 for v in iou], "mIoU": float(np.mean(np.array(iou))) * 100, "mP": float(np.mean(np.array(prec))),
+            "mR": float(np.mean(np.array(rec)))}
+
+
+def cam_threshold_sweep(cam_dicts, gts, num_cls=21, lo=35, hi=70):
+    """evaluation.py:159-175: sweep the background threshold, stop at the first non-improving value."""
+    best = (0, 0, None, None)
+    for i in range(lo, hi):
+        t = i / 100.0
+        preds = [cam_argmax_labels(d, t, num_cls) for d in cam_dicts]
+        m = seg_metrics(*seg_counts(preds, gts, num_cls))
+        if m["mIoU"] > best[0]:
+            best = (m["mIoU"], t, m["mP"], m["mR"])
+        else:
+            break
+    return best

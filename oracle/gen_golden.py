@@ -227,18 +227,85 @@ def case_lfca(mct, name, C, H, W, hd, wd):
     save(name, cam_diff=outs["cam_diff"], diff_cls=outs["diff_cls"], diff_pcls=outs["diff_pcls"], rcams=outs["rcams"])
 
 
+def synth_eval_set(C=20, seed=5):
+    """Small synthetic CAM dicts + ground-truth maps (with 255 boundary pixels) for the evaluation cases."""
+    rng = np.random.RandomState(seed)
+    dicts, gts = [], []
+    for n, (H, W) in enumerate([(37, 50), (64, 48), (33, 33), (40, 72)]):
+        keys = sorted(rng.choice(C, size=1 + n % 3, replace=False).tolist())
+        yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+        d = {k: np.clip(np.exp(-((yy - rng.uniform(0, H)) ** 2 + (xx - rng.uniform(0, W)) ** 2) / rng.uniform(40, 400))
+                        + 0.05 * rng.rand(H, W), 0, 1).astype(np.float32) for k in keys}
+        gt = np.zeros((H, W), np.uint8)
+        for k in keys:
+            gt[d[k] > 0.5] = k + 1
+        gt[rng.rand(H, W) < 0.05] = 255
+        dicts.append(d)
+        gts.append(gt)
+    return dicts, gts
+
+
+def case_eval(ev):
+    """(f)-3: the reference's own evaluation.do_python_eval on cam_dict / png files (evaluation.py:29-129) and its
+    threshold sweep rule (:159-175, restated around the reference's do_python_eval because eval_in_script hard-codes
+    ./data paths), against the oracle's seg_counts / seg_metrics / cam_threshold_sweep."""
+    import tempfile
+    from PIL import Image
+    dicts, gts = synth_eval_set()
+    arrays, d = {}, {}
+    with tempfile.TemporaryDirectory() as tmp:
+        names = []
+        for i, (cd, gt) in enumerate(zip(dicts, gts)):
+            np.save(os.path.join(tmp, f"img{i}.npy"), cd)       # model.py:489-492
+            Image.fromarray(gt).save(os.path.join(tmp, f"img{i}.png"))
+            names.append(f"img{i}")
+            arrays[f"gt{i}"] = gt
+            arrays[f"keys{i}"] = np.array(sorted(cd), np.int64)
+            arrays[f"cams{i}"] = np.stack([cd[k] for k in sorted(cd)])
+        worst = 0.0
+        for thr in (0.35, 0.5):
+            ref = ev.do_python_eval(tmp, tmp, names, 21, "cam", thr)
+            preds = [O.cam_argmax_labels(cd, thr, 21) for cd in dicts]
+            m = O.seg_metrics(*O.seg_counts(preds, gts, 21))
+            worst = max(worst, abs(ref["mIoU"] - m["mIoU"]), abs(ref["mP"] - m["mP"]), abs(ref["mR"] - m["mR"]),
+                        max(abs(ref[ev.categories[i]] - m["IoU"][i]) for i in range(21)))
+            arrays[f"ref_t{int(thr * 100)}"] = np.array([ref[ev.categories[i]] for i in range(21)] + [ref["mIoU"], ref["mP"], ref["mR"]], np.float64)
+        best, best_t = 0, 0
+        for i in range(35, 70):
+            r = ev.do_python_eval(tmp, tmp, names, 21, "cam", i / 100.0)
+            if r["mIoU"] > best:
+                best, best_t = r["mIoU"], i / 100.0
+            else:
+                break
+        ob = O.cam_threshold_sweep(dicts, gts, 21)
+        d["sweep_miou"] = abs(best - ob[0])
+        d["sweep_threshold"] = abs(best_t - ob[1])
+        arrays["sweep"] = np.array([best, best_t], np.float64)
+    d["metrics"] = worst
+    record("eval_cam", **d)
+    save("eval_cam", **arrays)
+
+
+def _merge_manifest():
+    mp = os.path.join(GOLD, "MANIFEST.json")
+    with open(mp) as f:
+        man = json.load(f)
+    man["cases"].update(MANIFEST)
+    with open(mp, "w") as f:
+        json.dump(man, f, indent=1)
+
+
 def main():
     assert ref_import.reference_available(), "reference not mounted - goldens can only be generated in the build container"
     mct = ref_import.load_mctformer()
     if sys.argv[1:] == ["lfca"]:  # add / refresh only the LFCA cases, keeping the rest of the manifest
         case_lfca(mct, "lfca224_c20", 20, 224, 224, 14, 14)
         case_lfca(mct, "lfca224_c20_maps16", 20, 224, 224, 16, 16)
-        mp = os.path.join(GOLD, "MANIFEST.json")
-        with open(mp) as f:
-            man = json.load(f)
-        man["cases"].update(MANIFEST)
-        with open(mp, "w") as f:
-            json.dump(man, f, indent=1)
+        _merge_manifest()
+        return
+    if sys.argv[1:] == ["eval"]:
+        case_eval(ref_import.load_evaluation())
+        _merge_manifest()
         return
     ddp = ref_import.load_ddp()
     case_schedule(ddp)
@@ -252,6 +319,7 @@ def main():
     case_cam(mct, "cam224_c80", 80, 224, 224, 1)
     case_lfca(mct, "lfca224_c20", 20, 224, 224, 14, 14)
     case_lfca(mct, "lfca224_c20_maps16", 20, 224, 224, 16, 16)  # guidance maps from a 256x256 diffusion input: bilinear 14 -> 16
+    case_eval(ref_import.load_evaluation())
     with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
         json.dump({"generator": "oracle/gen_golden.py", "torch": torch.__version__,
                    "what": "max-abs |reference - oracle| per output, fp32 CPU", "cases": MANIFEST,

@@ -97,3 +97,10 @@ def load_mctformer():
     if REF_ROOT not in sys.path:
         sys.path.insert(0, REF_ROOT)
     return importlib.import_module("networks.mctformer")
+
+
+def load_evaluation():
+    """Return the reference ``evaluation`` module (evaluation.py at the reference root: numpy, pandas, PIL, multiprocessing)."""
+    if REF_ROOT not in sys.path:
+        sys.path.insert(0, REF_ROOT)
+    return importlib.import_module("evaluation")

@@ -164,3 +164,63 @@ def test_update_forward_pipeline_vs_oracle():
     for k in ("rcams", "cam_diff", "diff_cls", "diff_pcls"):
         assert rel(outs[k], ro[k]) <= 1e-3, (k, rel(outs[k], ro[k]))
     assert rel(outs_diff["rcams"], rdiff) <= 1e-3
+
+
+def test_miou_evaluation_vs_oracle(tmp_path):
+    """SURVEY 8f-3 (evaluation.py:29-129,159-175; model.py:479-492): cam_dict files in the reference's format, device argmax +
+    P/T/TP counting - integer counts bit-exact against the numpy restatement, same metrics, same threshold-sweep result."""
+    from PIL import Image
+    from dig_amd import evaluation as E
+    rng = np.random.RandomState(5)
+    C, names, dicts, gts = 20, [], [], []
+    for n, (H, W) in enumerate([(37, 50), (64, 48), (33, 33)]):
+        keys = sorted(rng.choice(C, size=1 + n, replace=False).tolist())
+        yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+        d = {k: np.clip(np.exp(-((yy - rng.uniform(0, H)) ** 2 + (xx - rng.uniform(0, W)) ** 2) / rng.uniform(40, 400)) + 0.05 * rng.rand(H, W), 0, 1).astype(np.float32)
+             for k in keys}
+        gt = np.zeros((H, W), np.uint8)
+        for k in keys:
+            gt[d[k] > 0.5] = k + 1
+        gt[rng.rand(H, W) < 0.05] = 255
+        name = f"img{n}"
+        E.save_cam_dict(str(tmp_path / f"{name}.npy"), d)
+        Image.fromarray(gt).save(str(tmp_path / f"{name}.png"))
+        names.append(name), dicts.append(d), gts.append(gt)
+    for thr in (0.35, 0.5):
+        preds = [O.cam_argmax_labels(d, thr, C + 1) for d in dicts]
+        P, T, TP = O.seg_counts(preds, gts, C + 1)
+        ctr = E.SegCounter(C + 1, DEV)
+        for p_, g_ in zip(preds, gts):
+            ctr.add(torch.from_numpy(p_).to(DEV), torch.from_numpy(g_).to(DEV))
+        got = ctr.counts.cpu().numpy()
+        assert np.array_equal(got[0], P) and np.array_equal(got[1], T) and np.array_equal(got[2], TP)
+        res = E.do_python_eval(str(tmp_path), str(tmp_path), names, C + 1, "cam", thr, DEV)  # files -> device argmax -> counts
+        ref = O.seg_metrics(P, T, TP)
+        assert abs(res["mIoU"] - ref["mIoU"]) < 1e-9 and abs(res["mP"] - ref["mP"]) < 1e-12 and abs(res["mR"] - ref["mR"]) < 1e-12
+        assert all(abs(res[E.CATEGORIES[i]] - ref["IoU"][i]) < 1e-9 for i in range(C + 1))
+    sweep = E.threshold_sweep(lambda t: E.do_python_eval(str(tmp_path), str(tmp_path), names, C + 1, "cam", t, DEV))
+    rs = O.cam_threshold_sweep(dicts, gts, C + 1)
+    assert sweep[1] == rs[1] and abs(sweep[0] - rs[0]) < 1e-9
+
+
+def test_miou_evaluation_vs_reference_golden(golden):
+    """The same device path on the committed fixture whose metrics come from the reference's own evaluation.do_python_eval."""
+    from dig_amd import evaluation as E
+    g = golden("eval_cam")
+    C = 20
+    for thr in (0.35, 0.5):
+        ctr = E.SegCounter(C + 1, DEV)
+        i = 0
+        while f"gt{i}" in g:
+            cams, keys, gt = g[f"cams{i}"], g[f"keys{i}"], g[f"gt{i}"]
+            camt = torch.zeros(1, C, *gt.shape, device=DEV)
+            lab = torch.zeros(1, C, device=DEV)
+            for j, k in enumerate(keys):
+                camt[0, int(k)] = T(cams[j]).to(DEV)
+                lab[0, int(k)] = 1.0
+            ctr.add_cam(camt, lab, T(gt).to(DEV).reshape(1, *gt.shape), thr)
+            i += 1
+        r = ctr.result()
+        ref = g[f"ref_t{int(thr * 100)}"]
+        got = np.array([r[E.CATEGORIES[c]] for c in range(C + 1)] + [r["mIoU"], r["mP"], r["mR"]])
+        assert np.abs(got - ref).max() < 1e-9

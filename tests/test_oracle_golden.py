@@ -137,3 +137,25 @@ def test_lfca_consumer(golden):
     o = O.mctformer_lfca(sd, img, feat)
     for k in ("rcams", "cam_diff", "diff_cls", "diff_pcls"):
         assert (o[k] - T(g[k])).abs().max() <= TOL, k
+
+
+def _eval_set(g):
+    dicts, gts = [], []
+    i = 0
+    while f"gt{i}" in g:
+        dicts.append({int(k): g[f"cams{i}"][j] for j, k in enumerate(g[f"keys{i}"])})
+        gts.append(g[f"gt{i}"])
+        i += 1
+    return dicts, gts
+
+
+def test_eval_miou(golden):
+    """seg_counts / seg_metrics / cam_threshold_sweep against the reference's evaluation.do_python_eval outputs."""
+    g = golden("eval_cam")
+    dicts, gts = _eval_set(g)
+    for thr in (0.35, 0.5):
+        m = O.seg_metrics(*O.seg_counts([O.cam_argmax_labels(d, thr, 21) for d in dicts], gts, 21))
+        ref = g[f"ref_t{int(thr * 100)}"]
+        assert np.abs(np.array(m["IoU"] + [m["mIoU"], m["mP"], m["mR"]]) - ref).max() < 1e-9
+    best = O.cam_threshold_sweep(dicts, gts, 21)
+    assert abs(best[0] - g["sweep"][0]) < 1e-9 and best[1] == g["sweep"][1]
