@@ -4,6 +4,6 @@ cd /root/repo/dig_amd/csrc
 for spec in "$@"; do
   tag=${spec%%:*}; flags=${spec#*:}
   ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -ffp-contract=fast $flags -c gemm.hip -o /tmp/gemm_$tag.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "Function Name|VGPRs:|VGPRs Spill|Occupancy|error" | sed 's/remark: //; s/\[-Rpass.*//' | paste - - - - | grep DF16b | cut -c1-200;
-    /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 /tmp/gemm_$tag.o conv3x3.o conv3x3_ws.o elem.o linattn.o linattn_fused.o attn.o stem.o vit.o api.o -o /root/repo/scratch/lib_$tag.so ) &
+    /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 /tmp/gemm_$tag.o conv3x3.o conv3x3_ws.o elem.o linattn.o linattn_fused.o attn.o stem.o vit.o lfca.o api.o -o /root/repo/scratch/lib_$tag.so ) &
 done
 wait
