@@ -3,6 +3,8 @@
 // 12 x [B,6,N,N] probability tensors of the reference are never materialised), bicubic pos-embed resize,
 // CAM aggregation, flip-TTA + bilinear upsample + max_norm, and the argmax label map.
 // The linears of the ViT run on the f32 MFMA GEMM (gemm.hip); the pieces here are small and HBM/LDS bound.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -132,6 +134,159 @@ template <int DH> __global__ __launch_bounds__(256) void vit_attn_kernel(dig_vit
         const float mean = Pacc[qi * Np + j] / nh;  // torch.mean over heads (mctformer.py:303)
         a.acc_all[((size_t)b * N + q) * N + j] += mean;
         if (a.acc_cls && q < a.ncls) a.acc_cls[((size_t)b * a.ncls + q) * N + j] += mean;
+    }
+}
+
+
+// ---- the same on the fp32 matrix cores (N <= 320 tokens: 224x224 with up to 124 class tokens, or smaller images) ----------
+// Block = (32-query tile, image), loops over the heads.  Per head: V of the head is staged into LDS; S = Q K^T as 32x32 tiles (one key tile per wave at a
+// time, Q and K fragments straight from global/L2 rows); the scaled scores go to LDS, softmax with 8 lanes per query row
+// (each lane keeps its share of the head-sum in registers: no second LDS tile); O = P V with both operands from LDS, the
+// keys split over the waves.  The next head's V rows and all of a head's Q / K fragments are requested ahead of their use.
+// Exact fp32 products and fp32 accumulation (v_mfma_f32_32x32x2_f32), so the rolled-up probabilities keep the accuracy
+// the bit-exact argmax labels need.
+constexpr int TQM = 32, ATT_MAXE = 40, ATT_MAXKT = 3, ATT_MAXV = 20;
+template <int DH> __global__ __launch_bounds__(256, 1) void vit_attn_mfma_kernel(dig_vit_attn_args a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int N = a.N, nkt = (N + 31) / 32, NPk = nkt * 32, NP = NPk + 4;
+    float* Ps = sm;              // [32][NP] scores, then probabilities, of the current head
+    float* Vs = Ps + TQM * NP;   // [NPk][DH + 1] V of the current head (zero rows for keys >= N); also the P V partial-sum exchange
+    constexpr int VP = DH + 1;   // odd row pitch: the k-strided fragment reads of P V hit consecutive banks
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, q0 = blockIdx.x * TQM;
+    const int D3 = 3 * a.heads * DH, Dm = a.heads * DH;
+    const float* qkv = a.qkv + (size_t)b * N * D3;
+    const float scale = rsqrtf((float)DH);
+    const int srow = tid >> 3, sl = tid & 7, ne = NPk / 8;  // softmax: 8 lanes per query row, elements j = sl + 8 i
+    float pacc[ATT_MAXE];
+#pragma unroll
+    for (int i = 0; i < ATT_MAXE; i++) pacc[i] = 0.f;
+    const int qrow = min(q0 + r, N - 1);  // rows past the end repeat the last query; they are never stored
+    // V rows of head h as 16-byte pieces, one head ahead in registers (the block is alone on its CU: nothing else hides HBM/L2 latency)
+    const int nv = NPk * (DH / 4);
+    f32x4 vreg[ATT_MAXV];
+    auto vload = [&](int h) {
+#pragma unroll
+        for (int i = 0; i < ATT_MAXV; i++) {
+            const int idx = tid + i * 256, key = idx / (DH / 4), d4 = idx - key * (DH / 4);
+            vreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (idx < nv && key < N) vreg[i] = *reinterpret_cast<const f32x4*>(qkv + (size_t)key * D3 + 2 * Dm + h * DH + d4 * 4);
+        }
+    };
+    vload(0);
+    for (int h = 0; h < a.heads; h++) {
+        // this head's Q and K fragments: all requested up front so that their latencies overlap
+        Frag<float> fq[DH / 16], fk[ATT_MAXKT][DH / 16];
+#pragma unroll
+        for (int ks = 0; ks < DH / 16; ks++) frag_load<float>(fq[ks], qkv + (size_t)qrow * D3 + h * DH + ks * 16 + hf * 8);
+#pragma unroll
+        for (int t = 0; t < ATT_MAXKT; t++) {
+            const int kt = wave + 4 * t;
+            if (kt < nkt) {
+                const int key = min(kt * 32 + r, N - 1);
+#pragma unroll
+                for (int ks = 0; ks < DH / 16; ks++) frag_load<float>(fk[t][ks], qkv + (size_t)key * D3 + Dm + h * DH + ks * 16 + hf * 8);
+            }
+        }
+        __syncthreads();  // previous head's P V reads are done
+#pragma unroll
+        for (int i = 0; i < ATT_MAXV; i++) {
+            const int idx = tid + i * 256, key = idx / (DH / 4), d4 = idx - key * (DH / 4);
+            if (idx < nv) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) Vs[key * VP + d4 * 4 + j] = vreg[i][j];
+            }
+        }
+        if (h + 1 < a.heads) vload(h + 1);
+#pragma unroll
+        for (int t = 0; t < ATT_MAXKT; t++) {
+            const int kt = wave + 4 * t;
+            if (kt < nkt) {
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[e] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < DH / 16; ks++) mma16<float>(acc, fq[ks], fk[t][ks]);
+                const bool kval = kt * 32 + r < N;
+#pragma unroll
+                for (int e = 0; e < 16; e++) Ps[acc_row(e, lane) * NP + kt * 32 + r] = kval ? acc[e] * scale : -INFINITY;
+            }
+        }
+        __syncthreads();
+        {
+            float* row = Ps + srow * NP;
+            float m = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < ATT_MAXE; i++)
+                if (i < ne) m = fmaxf(m, row[sl + 8 * i]);
+            m = fmaxf(m, __shfl_xor(m, 1, 64));
+            m = fmaxf(m, __shfl_xor(m, 2, 64));
+            m = fmaxf(m, __shfl_xor(m, 4, 64));
+            float ev[ATT_MAXE], ssum = 0.f;
+#pragma unroll
+            for (int i = 0; i < ATT_MAXE; i++)
+                if (i < ne) {
+                    ev[i] = expf(row[sl + 8 * i] - m);
+                    ssum += ev[i];
+                }
+            ssum += __shfl_xor(ssum, 1, 64);
+            ssum += __shfl_xor(ssum, 2, 64);
+            ssum += __shfl_xor(ssum, 4, 64);
+            const float inv = 1.0f / ssum;
+#pragma unroll
+            for (int i = 0; i < ATT_MAXE; i++)
+                if (i < ne) {
+                    const float pv = ev[i] * inv;
+                    row[sl + 8 * i] = pv;
+                    pacc[i] += pv;
+                }
+        }
+        __syncthreads();
+        // O = P V: wave = (32-channel tile, key half) for DH = 64, (the tile, key quarter) for DH = 32; the partial sums meet in LDS
+        constexpr int DT = DH / 32, KSPLIT = 4 / DT;
+        const int dt = wave % DT, kpart = wave / DT;
+        const int nks = NPk / 16, ks0 = kpart * nks / KSPLIT, ks1 = (kpart + 1) * nks / KSPLIT;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[e] = 0.f;
+        for (int ks = ks0; ks < ks1; ks++) {
+            Frag<float> fp, fv;
+            frag_load<float>(fp, Ps + r * NP + ks * 16 + hf * 8);
+#pragma unroll
+            for (int j = 0; j < 8; j++) fv.v[j] = Vs[(ks * 16 + hf * 8 + j) * VP + dt * 32 + r];
+            mma16<float>(acc, fp, fv);
+        }
+        __syncthreads();  // every wave is done reading V: its rows become the exchange buffer [kpart][dt][32 q][33]
+        float* xb = Vs + ((kpart * DT + dt) * 32) * 33;
+        if (kpart > 0) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) xb[acc_row(e, lane) * 33 + r] = acc[e];
+        }
+        __syncthreads();
+        if (kpart == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                float v = acc[e];
+#pragma unroll
+                for (int kp = 1; kp < KSPLIT; kp++) v += Vs[((kp * DT + dt) * 32 + acc_row(e, lane)) * 33 + r];
+                const int q = q0 + acc_row(e, lane);
+                if (q < N) a.out[((size_t)b * N + q) * Dm + h * DH + dt * 32 + r] = v;
+            }
+        }
+    }
+    const float nh = (float)a.heads;
+    const int q = q0 + srow;
+    if (q < N) {
+#pragma unroll
+        for (int i = 0; i < ATT_MAXE; i++) {
+            const int j = sl + 8 * i;
+            if (i < ne && j < N) {
+                const float mean = pacc[i] / nh;  // torch.mean over heads (mctformer.py:303)
+                a.acc_all[((size_t)b * N + q) * N + j] += mean;
+                if (a.acc_cls && q < a.ncls) a.acc_cls[((size_t)b * a.ncls + q) * N + j] += mean;
+            }
+        }
     }
 }
 
@@ -275,6 +430,25 @@ extern "C" int dig_vit_attn(const dig_vit_attn_args* a, void* stream_) {
     STREAM;
     DIG_CHECK(a && a->qkv && a->out && a->acc_all, DIG_EINVAL, "vit_attn: null pointer");
     DIG_CHECK(a->B > 0 && a->N > 0 && a->heads > 0 && (a->dh == 64 || a->dh == 32), DIG_EINVAL, "vit_attn: bad shape (head dim must be 32 or 64)");
+    static const bool no_mfma = getenv("DIG_VIT_ATTN_NO_MFMA") != nullptr;  // test hook: keep the VALU kernel
+    if (a->N <= 8 * ATT_MAXE && !no_mfma) {
+        const int NP = (a->N + 31) / 32 * 32 + 4;
+        size_t vsz = (size_t)(NP - 4) * (a->dh + 1);  // V rows; reused as the 4 x [32][33] partial-sum exchange of P V
+        if (vsz < 4 * 32 * 33) vsz = 4 * 32 * 33;
+        const size_t ldsm = ((size_t)TQM * NP + vsz) * sizeof(float);
+        const dim3 gridm(cdiv(a->N, TQM), a->B);
+        hipError_t e = hipSuccess;
+        if (a->dh == 64) {
+            e = hipFuncSetAttribute((const void*)vit_attn_mfma_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm);
+            if (e == hipSuccess) hipLaunchKernelGGL(vit_attn_mfma_kernel<64>, gridm, dim3(256), ldsm, stream, *a);
+        } else {
+            e = hipFuncSetAttribute((const void*)vit_attn_mfma_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm);
+            if (e == hipSuccess) hipLaunchKernelGGL(vit_attn_mfma_kernel<32>, gridm, dim3(256), ldsm, stream, *a);
+        }
+        DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "vit_attn: cannot raise dynamic LDS to %zu: %s", ldsm, hipGetErrorString(e));
+        DIG_LAUNCH_CHECK("vit_attn");
+        return DIG_OK;
+    }
     const int Np = (a->N + 3) & ~3;
     const size_t lds = (size_t)(2 * TQ * Np + TQ * a->dh) * sizeof(float);
     DIG_CHECK(lds <= 150 * 1024, DIG_EINVAL, "vit_attn: %d tokens need %zu B of LDS (max 150 KiB)", a->N, lds);
