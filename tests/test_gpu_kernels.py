@@ -364,3 +364,26 @@ def test_lfca_helper_kernels(dt):
         call("bilinear_resize", **{"in": xd}, res=nhwc(rr, dt), out=out, B=B, hi=H, wi=W, ho=ho, wo=wo, C=C, dtype=dtype_code(dt))
         ref = F.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=False) + rr
         assert (nchw(out) - ref).abs().max() <= (1e-5 if dt == torch.float32 else tol(dt, ref)), (ho, wo)
+
+
+@pytest.mark.parametrize("cfg", [(2, 36, 3, 64), (1, 216, 6, 64), (2, 100, 2, 32), (1, 330, 2, 64), (3, 7, 1, 32)])
+def test_vit_attn_rollout(cfg):
+    """dig_vit_attn (vision_transformer.py:87-103 + the head-mean / layer-sum of mctformer.py:302-315): output tokens and the
+    two probability accumulators against torch, over two layers.  N <= 320 runs on the fp32 matrix cores, N = 330 on the VALU
+    kernel; ragged token counts, both head widths."""
+    B, N, heads, dh = cfg
+    ncls, D = min(5, N), heads * dh
+    acc_all = torch.zeros(B, N, N, device=DEV)
+    acc_cls = torch.zeros(B, ncls, N, device=DEV)
+    ref_all = torch.zeros(B, N, N)
+    for layer in range(2):
+        qkv = rnd(f"va{layer}", (B, N, 3 * D), 1.5)
+        q, k, v = qkv.reshape(B, N, 3, heads, dh).permute(2, 0, 3, 1, 4)
+        p = ((q @ k.transpose(-2, -1)) * dh ** -0.5).softmax(-1)
+        ref_o = (p @ v).transpose(1, 2).reshape(B, N, D)
+        ref_all += p.mean(1)
+        out = torch.empty(B, N, D, device=DEV)
+        call("vit_attn", qkv=qkv.to(DEV), out=out, acc_all=acc_all, acc_cls=acc_cls if layer == 1 else None, B=B, N=N, heads=heads, dh=dh, ncls=ncls)
+        assert (out.cpu() - ref_o).abs().max() <= 2e-5 * max(1.0, float(ref_o.abs().max()))
+    assert (acc_all.cpu() - ref_all).abs().max() <= 2e-6
+    assert (acc_cls.cpu() - p.mean(1)[:, :ncls]).abs().max() <= 2e-6
