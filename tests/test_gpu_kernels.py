@@ -387,3 +387,67 @@ def test_vit_attn_rollout(cfg):
         assert (out.cpu() - ref_o).abs().max() <= 2e-5 * max(1.0, float(ref_o.abs().max()))
     assert (acc_all.cpu() - ref_all).abs().max() <= 2e-6
     assert (acc_cls.cpu() - p.mean(1)[:, :ncls]).abs().max() <= 2e-6
+
+
+def test_conv3x3_random_shapes():
+    """Seeded sweep over ragged shapes and channel combinations (every conv3x3 dispatch class: weight-stationary, double-buffered,
+    generic bf16/fp32; concat / nearest-x2 / prologue), bf16 and fp32, against F.conv2d."""
+    rng = np.random.RandomState(20261110)
+    for it in range(24):
+        dt = DTYPES[it % 2]
+        Co = int(rng.choice([16, 32, 64, 128, 256]))
+        C0 = int(rng.choice([16, 32, 64, 128, 192]))
+        mode = it % 4  # 0 plain, 1 concat, 2 up2, 3 prologue
+        C1 = int(rng.choice([16, 64])) if mode == 1 else 0
+        B = int(rng.randint(1, 3))
+        H, W = (int(rng.randint(1, 24)) * 2, int(rng.randint(1, 24)) * 2) if mode == 2 else (int(rng.randint(1, 45)), int(rng.randint(1, 45)))
+        if it % 6 == 0:
+            H, W, C0, Co, C1, mode = 16 * int(rng.randint(1, 4)), 16 * int(rng.randint(1, 4)), 64, 64, 0, 3 * (it % 12 == 0)  # weight-stationary class
+        tag = f"r{it}"
+        w, b = q(rnd(tag + "w", (Co, C0 + C1, 3, 3), (3.0 / (9 * (C0 + C1))) ** 0.5), dt), rnd(tag + "b", (Co,), 0.1)
+        cw = ops.ConvWeight(w.to(DEV), b.to(DEV), dt, C1=C1)
+        if mode == 2:
+            xs = q(rnd(tag + "x", (B, C0, H // 2, W // 2)), dt)
+            ref = F.conv2d(F.interpolate(xs, scale_factor=2, mode="nearest"), w, b, padding=1)
+            y, _ = ops.conv3x3(nhwc(xs, dt), cw, up2=True, want_stats=False)
+            k = 1
+        else:
+            x0 = q(rnd(tag + "x", (B, C0, H, W)), dt)
+            x1 = q(rnd(tag + "y", (B, C1, H, W)), dt) if C1 else None
+            aff, k = None, 1
+            xin = torch.cat([x0, x1], 1) if C1 else x0
+            if mode == 3:
+                aff = torch.stack([1.0 + 0.3 * rnd(tag + "a", (B, C0)), 0.2 * rnd(tag + "c", (B, C0))], -1)
+                xin = q(F.silu(x0 * aff[..., 0][:, :, None, None] + aff[..., 1][:, :, None, None]), dt)
+                k = 1 if dt == torch.float32 else 2
+            ref = F.conv2d(xin, w, b, padding=1)
+            y, st = ops.conv3x3(nhwc(x0, dt), cw, x1=nhwc(x1, dt) if C1 else None, aff=aff.to(DEV).contiguous() if aff is not None else None)
+            g = ref.reshape(B, 8, -1).double()
+            assert torch.allclose(st.cpu().double().sum(2)[..., 0], g.sum(-1), rtol=1e-3, atol=2e-2 * g.shape[-1] ** 0.5), (it, "stats")
+        assert (nchw(y) - ref).abs().max() <= k * tol(dt, ref), (it, dt, B, C0, C1, Co, H, W, mode)
+
+
+def test_gemm_random_shapes():
+    """Seeded sweep over M, N, K (ragged tiles, K with and without the multiple-of-32 that selects the LDS-DMA kernel), the concat
+    loader, bias / residual / GELU epilogues, bf16 and fp32, against F.linear."""
+    rng = np.random.RandomState(7)
+    for it in range(24):
+        dt = DTYPES[it % 2]
+        M, N = int(rng.randint(1, 700)), int(rng.randint(1, 40)) * 8
+        K0 = int(rng.choice([8, 32, 64, 96, 136, 256, 512]))
+        K1 = int(rng.choice([0, 0, 32, 64]))
+        tag = f"g{it}"
+        x0 = q(rnd(tag + "x", (M, K0)), dt)
+        x1 = q(rnd(tag + "y", (M, K1)), dt) if K1 else None
+        w, b = q(rnd(tag + "w", (N, K0 + K1), (K0 + K1) ** -0.5), dt), rnd(tag + "b", (N,), 0.1)
+        res = q(rnd(tag + "r", (M, N)), dt) if it % 3 == 0 else None
+        gelu = it % 4 == 1
+        xin = torch.cat([x0, x1], 1) if K1 else x0
+        ref = F.linear(xin, w, b)
+        if gelu:
+            ref = F.gelu(ref)
+        if res is not None:
+            ref = ref + res
+        dev = lambda t: t.to(device=DEV, dtype=dt)
+        y = ops.linear_rows(dev(x0), dev(w), bias=b.to(DEV), x1=dev(x1) if K1 else None, res=dev(res) if res is not None else None, gelu=gelu)
+        assert (y.float().cpu() - ref).abs().max() <= tol(dt, ref), (it, dt, M, N, K0, K1)
