@@ -180,3 +180,31 @@ def test_unet_full_size_properties():
         assert (v1 - v[i:i + 1]).abs().max() <= 2e-2 * max(1.0, float(v.abs().max()))
         for a, b in zip(f1, feats):
             assert (a - b[i:i + 1]).abs().max() <= 2e-2 * max(1.0, float(b.abs().max()))
+
+
+def _pack_la(m, dt):
+    """the LinearAttention branch of diffusion._pack_unet's attn() packer"""
+    from dig_amd.diffusion import _conv1_pack
+    hid = m.heads * 32
+    d = {"full": False, "heads": m.heads, "g": m.norm.g.reshape(-1).float().contiguous()}
+    wqkv, _ = _conv1_pack(m.to_qkv, dt)
+    d["wq"], d["wkv"] = wqkv[:hid].contiguous(), wqkv[hid:].contiguous()
+    wg = (m.to_qkv.weight.detach().float().reshape(3 * hid, -1) * m.norm.g.detach().float().reshape(1, -1))
+    d["wq_g"], d["wkv_g"] = wg[:hid].contiguous().to(dt), wg[hid:].contiguous().to(dt)
+    d["wo"], d["bo"] = _conv1_pack(m.to_out[0], dt)
+    d["g2"] = m.to_out[1].g.reshape(-1).float().contiguous()
+    return d
+
+
+@pytest.mark.parametrize("dt,tl", [(torch.float32, 3e-4), (torch.bfloat16, 5e-2)])
+@pytest.mark.parametrize("C,H,W,B", [(64, 16, 24, 2), (128, 24, 40, 2), (256, 8, 12, 3), (128, 64, 64, 1), (256, 32, 48, 1), (16, 8, 8, 1)])
+def test_linear_attention_widths(dt, tl, C, H, W, B):
+    """Fused LinearAttention at every channel width of the Unet (LDS-resident weights for C <= 64, 8-wave blocks for C = 128,
+    M_b-only residency for C = 256), several pixel counts (1..8 sub-tiles per wave), against the CPU oracle (ddp.py:196-233)."""
+    la = fill(D.LinearAttention(C), f"law{C}").to(DEV)
+    x = synth.uniform_pm1(f"law.x{C}", (B, C, H, W))
+    w = {k: v.detach().cpu().float() for k, v in la.state_dict().items()}
+    xq = x.to(dt).float()
+    ref = O.linear_attention(w, xq) + xq
+    y = D._linear_attention(_pack_la(la, dt), nhwc(x, dt))
+    assert (nchw(y) - ref).abs().max() <= tl * max(1.0, float(ref.abs().max()))
