@@ -224,3 +224,29 @@ def test_miou_evaluation_vs_reference_golden(golden):
         ref = g[f"ref_t{int(thr * 100)}"]
         got = np.array([r[E.CATEGORIES[c]] for c in range(C + 1)] + [r["mIoU"], r["mP"], r["mR"]])
         assert np.abs(got - ref).max() < 1e-9
+
+
+def test_cam_full_batch_properties():
+    """BASELINE.json configs[2] at bench size (B = 32, 224x224, C = 20), where a CPU oracle run does not fit the test budget:
+    two runs are bitwise identical (the probability roll-up uses no atomics), an image alone gives the same CAM and the same
+    uint8 labels as inside the batch, flipping the input flips infer_multi's TTA result, CAMs are max-normalised to [0, 1]."""
+    B, C, S = 32, 20, 224
+    m = make_mct(C)
+    img = synth.synth_imagenet_images(B, S, S, seed=123).to(DEV)
+    label = synth.synth_labels(B, C, seed=17).to(DEV)
+    rc = m(img, return_att=True)
+    assert torch.equal(rc, m(img, return_att=True)) and tuple(rc.shape) == (B, C, 14, 14) and torch.isfinite(rc).all()
+    norm = cam.infer_multi_cam(m, img, label, 12)
+    assert float(norm.min()) >= 0.0 and float(norm.max()) <= 1.0
+    labs = cam.cam_labels(norm, label, 0.45)
+    for i in (0, 13, 31):
+        r1 = m(img[i:i + 1], return_att=True)
+        assert float((r1 - rc[i:i + 1]).abs().max()) <= 1e-5 * max(1.0, float(rc.abs().max()))
+        n1 = cam.infer_multi_cam(m, img[i:i + 1], label[i:i + 1], 12)
+        assert float((n1 - norm[i:i + 1]).abs().max()) <= 1e-5
+        l1 = cam.cam_labels(n1, label[i:i + 1], 0.45)
+        assert int((l1 != labs[i:i + 1]).sum()) <= int(0.0005 * S * S)  # only exact-tie pixels may differ between batch sizes
+    nf = cam.infer_multi_cam(m, torch.flip(img[:4], (3,)), label[:4], 12)
+    dflip = float((torch.flip(nf, (3,)) - norm[:4]).abs().max())
+    print('flip symmetry max diff', dflip)
+    assert dflip <= 1e-4
