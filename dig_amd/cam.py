@@ -66,25 +66,27 @@ def _pos_embed(m, P, H, W):
 
 
 def _pack_lfca(m):
-    key = (next(m.parameters()).device, sum(p._version for p in m.parameters()), m.LFCA0.query.weight.data_ptr())
+    dt = m.lfca_dtype
+    key = (next(m.parameters()).device, sum(p._version for p in m.parameters()), m.LFCA0.query.weight.data_ptr(), dt)
     if m._packed_lfca is not None and m._packed_lfca["key"] == key:
         return m._packed_lfca
     f = lambda t: t.detach().float().contiguous()
-    mat = lambda conv: f(conv.weight.reshape(conv.weight.shape[0], -1))
+    mat = lambda conv: conv.weight.detach().reshape(conv.weight.shape[0], -1).contiguous().to(dt)   # storage type of the big GEMMs
     wb = lambda mod: (f(mod.weight), f(mod.bias))
+    wbd = lambda mod: (mod.weight.detach().contiguous().to(dt), f(mod.bias))
     zeros = lambda n: torch.zeros(n, dtype=F32, device=m.head.weight.device)
-    P = {"key": key}
+    P = {"key": key, "dtype": dt}
     for name in ("LFCA0", "LFCA1"):
         L = getattr(m, name)
         di = L.diff_init
         P[name] = dict(
-            c1=ops.ConvWeight(di.convbnrelu1[0].weight, zeros(m.D_f), F32), gn1=wb(di.convbnrelu1[1]),
-            c2=ops.ConvWeight(di.convbn2[0].weight, zeros(m.D_f), F32), gn2=wb(di.convbn2[1]), branch=mat(di.branch),
+            c1=ops.ConvWeight(di.convbnrelu1[0].weight, zeros(m.D_f), dt), gn1=wb(di.convbnrelu1[1]),
+            c2=ops.ConvWeight(di.convbn2[0].weight, zeros(m.D_f), dt), gn2=wb(di.convbn2[1]), branch=mat(di.branch),
             norm_k=wb(L.norm_k), norm_v=wb(L.norm_v), norm_p1=wb(L.norm_p1), norm_c1=wb(L.norm_c1),
-            query=wb(L.query), key=(mat(L.key), f(L.key.bias)), value=ops.ConvWeight(L.value.weight, L.value.bias, F32),
-            mlp_c0=wb(L.mlp_c0), mlp_p0=ops.ConvWeight(L.mlp_p0.weight, L.mlp_p0.bias, F32),
+            query=wb(L.query), key=(mat(L.key), f(L.key.bias)), value=ops.ConvWeight(L.value.weight, L.value.bias, dt),
+            mlp_c0=wb(L.mlp_c0), mlp_p0=ops.ConvWeight(L.mlp_p0.weight, L.mlp_p0.bias, dt),
             c1a=wb(L.mlp_c1[0]), c1b=wb(L.mlp_c1[2]), p1a=(mat(L.mlp_p1[0]), f(L.mlp_p1[0].bias)), p1b=(mat(L.mlp_p1[2]), f(L.mlp_p1[2].bias)))
-    P["head0"] = ops.ConvWeight(m.diff_head_p[0].weight, m.diff_head_p[0].bias, F32)
+    P["head0"] = ops.ConvWeight(m.diff_head_p[0].weight, m.diff_head_p[0].bias, dt)
     P["head2"] = (mat(m.diff_head_p[2]), f(m.diff_head_p[2].bias))
     m._packed_lfca = P
     return P
@@ -96,7 +98,16 @@ def _affine(x, aff=None, res=None, pre=0, post=0, xs=1.0, rs=1.0):
     C = x.shape[-1]
     B = x.shape[0]
     call("affine_act_add", x=x, aff=aff, res=res, out=out, B=B, HW=x.numel() // (B * C), C=C, pre_act=pre, post_act=post,
-         dtype=1, x_scale=float(xs), res_scale=float(rs))
+         dtype=ops.dtype_code(x.dtype), x_scale=float(xs), res_scale=float(rs))
+    return out
+
+
+def _cast(x, dt):
+    """storage-type conversion (dig_cast); identity when x already has dt"""
+    if x.dtype == dt:
+        return x
+    out = torch.empty(x.shape, dtype=dt, device=x.device)
+    call("cast", **{"in": x.contiguous()}, out=out, n=x.numel(), to_f32=int(dt == F32))
     return out
 
 
@@ -108,7 +119,9 @@ def _gn1(stats, wb, hw, eps):
 
 
 def lfca_forward(L, qkv, C, feat, heads=8):
-    """LFCA.forward in eval mode (mctformer.py:124-166) on the HIP kernels, fp32.
+    """LFCA.forward in eval mode (mctformer.py:124-166) on the HIP kernels.  The convolutions and the wide 1x1 GEMMs run in the
+    storage type of `feat` (fp32, or bf16 with fp32 accumulation = what torch.autocast would pick for them); LayerNorm,
+    GroupNorm statistics, the cross attention and the class-token branch are always fp32.
     qkv [B, C+N, 3D]: output of a ViT block's qkv Linear (its first D columns are the un-scaled query in the
     [B, C+N, D] layout of mctformer.py:280-281); feat NHWC [B, hd, wd, 5*D_f].  -> (x_c [B, C, D], x_p NHWC [B, hd, wd, D_f])."""
     B, Nq, D3 = qkv.shape
@@ -118,10 +131,12 @@ def lfca_forward(L, qkv, C, feat, heads=8):
     _, hd, wd, _ = feat.shape
     Nf = hd * wd
     dev = qkv.device
+    dt = feat.dtype
+    gg = 16 if dt == F32 else 8  # GroupNorm partials per 64- / 128-channel slice (the conv's N tile); folded into the single group below
     # diff_init = ResBlock_ysh(5*D_f, D_f, groups=1) (resnet101.py:195-222)
-    h1, st = ops.conv3x3(feat, L["c1"], groups=16)  # partial sums per 64-channel slice; folded into the single group below
+    h1, st = ops.conv3x3(feat, L["c1"], groups=gg)
     a1 = _affine(h1, _gn1(st, L["gn1"], Nf, 1e-5), pre=2)
-    h2, st = ops.conv3x3(a1, L["c2"], groups=16)
+    h2, st = ops.conv3x3(a1, L["c2"], groups=gg)
     br = ops.linear_rows(feat, L["branch"])
     kv = _affine(h2, _gn1(st, L["gn2"], Nf, 1e-5), res=br, post=2)
     Df = kv.shape[-1]
@@ -129,8 +144,8 @@ def lfca_forward(L, qkv, C, feat, heads=8):
     q = torch.empty(B, Nq, D, dtype=F32, device=dev)
     ops.gemm_nt(qkv, L["query"][0], q, B * Nq, D, D, dtype=F32, lda0=D3, bias=L["query"][1])
     q = _layernorm(q, L["norm_k"])
-    k = _layernorm(ops.linear_rows(kv, L["key"][0], bias=L["key"][1]), L["norm_k"])             # [B,hd,wd,D]
-    v = _layernorm(ops.conv3x3(kv, L["value"], want_stats=False)[0], L["norm_v"])               # [B,hd,wd,Df]
+    k = _layernorm(ops.linear_rows(kv, L["key"][0], bias=L["key"][1], out_f32=True), L["norm_k"])    # [B,hd,wd,D] fp32
+    v = _layernorm(_cast(ops.conv3x3(kv, L["value"], want_stats=False)[0], F32), L["norm_v"])        # [B,hd,wd,Df] fp32
     # 8-head cross attention (mctformer.py:138-151).  The key count (196 at 224x224) need not be a multiple of the GEMM's
     # 8-element K vectors: the logits live in rows of Nfp >= Nf columns whose tail is -inf (softmax -> exactly 0 there), and
     # v^T gets 8 floats of zero slack so the last row's vector tail stays inside the buffer.
@@ -153,15 +168,16 @@ def lfca_forward(L, qkv, C, feat, heads=8):
     hdn = ops.linear_rows(y, L["c1a"][0], bias=L["c1a"][1], gelu=True)
     x_c = ops.linear_rows(hdn, L["c1b"][0], bias=L["c1b"][1], res=x_c)
     # patch branch (mctformer.py:154,160-164): rows [C:] of o are NHWC [B, ht, wt, Df] with batch stride Nq*Df
-    o_p = torch.empty(B, ht, wt, Df, dtype=F32, device=dev)
+    o_p = torch.empty(B, ht, wt, Df, dtype=dt, device=dev)
     cw = L["mlp_p0"]
-    call("conv3x3", in0=o.data_ptr() + C * Df * 4, in1=None, aff0=None, w=cw.w, bias=cw.bias, out=o_p, stats=None,
-         in0_bstride=Nq * Df, B=B, H=ht, W=wt, C0=Df, C1=0, Cout=Df, groups=1, up2=0, dtype=1)
-    x_p = torch.empty(B, hd, wd, Df, dtype=F32, device=dev)
-    call("bilinear_resize", **{"in": o_p}, res=kv, out=x_p, B=B, hi=ht, wi=wt, ho=hd, wo=wd, C=Df, dtype=1)
+    od = _cast(o, dt)
+    call("conv3x3", in0=od.data_ptr() + C * Df * od.element_size(), in1=None, aff0=None, w=cw.w, bias=cw.bias, out=o_p, stats=None,
+         in0_bstride=Nq * Df, B=B, H=ht, W=wt, C0=Df, C1=0, Cout=Df, groups=1, up2=0, dtype=ops.dtype_code(dt))
+    x_p = torch.empty(B, hd, wd, Df, dtype=dt, device=dev)
+    call("bilinear_resize", **{"in": o_p}, res=kv, out=x_p, B=B, hi=ht, wi=wt, ho=hd, wo=wd, C=Df, dtype=ops.dtype_code(dt))
     tiles = min(Nf, 16)
     st = torch.empty(B, 1, tiles, 2, dtype=F32, device=dev)
-    call("gn_stats", x=x_p, stats=st, B=B, HW=Nf, C=Df, groups=1, tiles=tiles, dtype=1)
+    call("gn_stats", x=x_p, stats=st, B=B, HW=Nf, C=Df, groups=1, tiles=tiles, dtype=ops.dtype_code(dt))
     y = _affine(x_p, _gn1(st, L["norm_p1"], Nf, 1e-6))
     hdn = ops.linear_rows(y, L["p1a"][0], bias=L["p1a"][1], gelu=True)
     x_p = ops.linear_rows(hdn, L["p1b"][0], bias=L["p1b"][1], res=x_p)
@@ -223,13 +239,13 @@ def mctformer_forward(m, img, n_layers=12, feat_diff=None):
         hd, wd = feat_diff[0].shape[2:]
         # torch.stack(feat_diff, 1).view(n, -1, h, w) (mctformer.py:275): timestep-major channels, then NHWC for the kernels
         cat = torch.stack([t.float() for t in feat_diff], dim=1).reshape(B, -1, hd, wd).contiguous()
-        feat = ops.nchw_to_nhwc(cat, F32)
+        feat = ops.nchw_to_nhwc(cat, PL["dtype"])
         c0, p0 = lfca_forward(PL["LFCA0"], qkv_last[1], C, feat)   # query0 = q of the last block (mctformer.py:280)
         c1, p1 = lfca_forward(PL["LFCA1"], qkv_last[0], C, feat)   # query1 = q of the one before
         out_p = _affine(p0, res=p1, xs=0.5, rs=0.5)                # (p0 + p1) / 2 (mctformer.py:287)
         out_c = (c0 + c1) / 2
         hh = _affine(ops.conv3x3(out_p, PL["head0"], want_stats=False)[0], pre=2)
-        cd = ops.nhwc_to_nchw_f32(ops.linear_rows(hh, PL["head2"][0], bias=PL["head2"][1]))  # [B,20,hd,wd], pre-ReLU
+        cd = ops.nhwc_to_nchw_f32(ops.linear_rows(hh, PL["head2"][0], bias=PL["head2"][1], out_f32=True))  # [B,20,hd,wd], pre-ReLU
         cv = cd.reshape(B, cd.shape[1], -1)
         kk = min(3, cv.shape[-1])
         outs["cam_diff"] = cd.clamp_min(0)

@@ -138,6 +138,30 @@ inline int grid_for(size_t work, int block, int cap = 256 * 8) {
 
 }  // namespace
 
+namespace {
+template <typename TI, typename TO> __global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, long long nvec) {
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.x * 256) {
+        Frag<TI> f;
+        Frag<TO> o;
+        frag_load<TI>(f, in + v * 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) frag_set<TO>(o, j, frag_get<TI>(f, j));
+        frag_store<TO>(o, out + v * 8);
+    }
+}
+}  // namespace
+
+extern "C" int dig_cast(const dig_cast_args* a, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    DIG_CHECK(a && a->in && a->out && a->n > 0 && a->n % 8 == 0, DIG_EINVAL, "cast: n must be a positive multiple of 8");
+    DIG_CHECK(((uintptr_t)a->in | (uintptr_t)a->out) % 16 == 0, DIG_EALIGN, "cast: pointers must be 16-byte aligned");
+    const int g = grid_for((size_t)(a->n / 8), 256);
+    if (a->to_f32) hipLaunchKernelGGL((cast_kernel<bf16, float>), dim3(g), dim3(256), 0, stream, (const bf16*)a->in, (float*)a->out, a->n / 8);
+    else hipLaunchKernelGGL((cast_kernel<float, bf16>), dim3(g), dim3(256), 0, stream, (const float*)a->in, (bf16*)a->out, a->n / 8);
+    DIG_LAUNCH_CHECK("cast");
+    return DIG_OK;
+}
+
 extern "C" int dig_affine_act_add(const dig_affine_act_add_args* a, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     DIG_CHECK(a && a->x && a->out, DIG_EINVAL, "affine_act_add: null pointer");

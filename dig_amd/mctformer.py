@@ -92,6 +92,7 @@ class MCTformerV2_DiG(nn.Module):
             # the reference hard-codes 20 output maps here whatever num_classes is (mctformer.py:189)
             self.diff_head_p = nn.Sequential(nn.Conv2d(self.D_f, self.D_f, 3, 1, 1), nn.ReLU(inplace=True), nn.Conv2d(self.D_f, 20, 1, 1, 0))
         self.has_lfca = bool(lfca)
+        self.lfca_dtype = torch.float32  # storage type of the LFCA convolutions / wide GEMMs: float32 (parity) or bfloat16 (fast)
         self._packed = None
         self._packed_lfca = None
 
@@ -104,6 +105,15 @@ class MCTformerV2_DiG(nn.Module):
                 raise NotImplementedError("the LFCA branch is forward-only here (DropPath 0.1 is a training feature); call .eval()")
         outs = cam.mctformer_forward(self, x, n_layers, feat_diff=feat_diff)
         return outs["rcams"] if return_att else outs
+
+
+def _set_lfca_dtype(self, dtype):
+    assert dtype in (torch.float32, torch.bfloat16)
+    self.lfca_dtype = dtype
+    return self
+
+
+MCTformerV2_DiG.set_lfca_dtype = _set_lfca_dtype
 
 
 def deit_small_MCTformerV2_DiG(pretrained=False, **kwargs):

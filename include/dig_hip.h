@@ -445,6 +445,16 @@ typedef struct {
 } dig_seg_hist_args;
 int dig_seg_hist(const dig_seg_hist_args* a, void* stream);
 
+/* storage-type conversion between the bf16 convolutions / GEMMs and the fp32 LayerNorm / attention of the LFCA consumer
+ * (what torch.autocast inserts around those ops): to_f32 = 1: bf16 -> fp32, 0: fp32 -> bf16 (round to nearest even). n % 8 == 0. */
+typedef struct {
+    const void* in;
+    void* out;
+    long long n;
+    int to_f32;
+} dig_cast_args;
+int dig_cast(const dig_cast_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

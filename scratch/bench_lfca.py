@@ -18,4 +18,7 @@ def timeit(fn, n=5):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 t0 = timeit(lambda: m(img))
 t1 = timeit(lambda: m(img, feat_diff=feat))
+m.set_lfca_dtype(torch.bfloat16)
+t2 = timeit(lambda: m(img, feat_diff=feat))
+print(f"bf16 storage for the LFCA convolutions: {t2:.2f} ms -> LFCA part {t2 - t0:.2f} ms = {B * 74.0 / (t2 - t0):.1f} TFLOP/s")
 print(f"B={B} 224x224: ViT/CAM forward {t0:.2f} ms; with LFCA0/1 + diff_head_p {t1:.2f} ms -> LFCA part {t1 - t0:.2f} ms = {B * 74.0 / (t1 - t0):.1f} TFLOP/s (74 GFLOP/img, fp32)")

@@ -250,3 +250,21 @@ def test_cam_full_batch_properties():
     dflip = float((torch.flip(nf, (3,)) - norm[:4]).abs().max())
     print('flip symmetry max diff', dflip)
     assert dflip <= 1e-4
+
+
+def test_lfca_consumer_bf16_storage(golden):
+    """The LFCA branch with bf16 storage for its convolutions / wide GEMMs (fp32 accumulation, fp32 LayerNorm / attention):
+    against the fp32 reference outputs within 3e-2 of the output range - the tolerance class of the bf16 Unet."""
+    g = golden("lfca224_c20")
+    m = create_model("deit_small_MCTformerV2_DiG", pretrained=False, num_classes=20, lfca=True)
+    synth.fill_state_dict(m, seed=0, skip_prefixes=("norm.",))
+    m = m.to(DEV).eval().set_lfca_dtype(torch.bfloat16)
+    img = synth.synth_imagenet_images(1, 224, 224, seed=4400).to(DEV)
+    feat = [(synth.normal("feat_diff", (1, 1024, 14, 14), seed=7 + j) * 1.5).to(DEV) for j in range(5)]
+    outs = m(img, feat_diff=feat)
+    for k in ("cam_diff", "diff_cls", "diff_pcls"):
+        ref = T(g[k])
+        err = float((outs[k].cpu() - ref).abs().max())
+        print("bf16", k, err, float(ref.abs().max()))
+        assert err <= 3e-2 * max(1.0, float(ref.abs().max())), (k, err)
+    assert float((outs["rcams"].cpu() - T(g["rcams"])).abs().max()) <= 1e-4  # the ViT / CAM part stays fp32
