@@ -30,8 +30,8 @@ PEAK_F32_TFLOPS = 157.3
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
