@@ -83,10 +83,22 @@ def _ptr(x):
 
 def call(fn, stream=None, **kw):
     """Call `int dig_<fn>(const dig_<fn>_args*, void* stream)` with keyword fields; tensors become pointers.
-    `stream` defaults to torch's current HIP stream.  Raises RuntimeError on a non-zero return."""
+    The launch goes to the device the tensor arguments live on (they must all share one HIP device; CPU tensors and
+    mixed devices raise before anything is launched), on that device's current torch stream unless `stream` is given.
+    Raises RuntimeError on a non-zero return."""
     import torch
 
     L = lib()
+    dev = None
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            if not v.is_cuda:
+                raise RuntimeError(f"dig_{fn}: argument {k!r} is a {v.device} tensor; the kernels take HIP-device pointers only "
+                                   "(no CPU fallback) - move the module and its inputs to the device first")
+            if dev is None:
+                dev = v.device
+            elif v.device != dev:
+                raise RuntimeError(f"dig_{fn}: argument {k!r} lives on {v.device} but another argument on {dev}")
     sname = {"gemm_nt": "dig_gemm_args", "qsample_stem": "dig_stem_args", "bilinear_ac_concat": "dig_bilinear_ac_args",
              "nchw_f32_to_nhwc": "dig_layout_args", "nhwc_to_nchw_f32": "dig_layout_args"}.get(fn, f"dig_{fn}_args")
     S = STRUCTS[sname]
@@ -102,9 +114,15 @@ def call(fn, stream=None, **kw):
             setattr(args, k, ftype(*v))
         else:
             setattr(args, k, v)
-    if stream is None:
-        stream = torch.cuda.current_stream().cuda_stream
-    rc = getattr(L, "dig_" + fn)(ctypes.byref(args), ctypes.c_void_p(stream))
+    if dev is None or dev.index in (None, torch.cuda.current_device()):
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        rc = getattr(L, "dig_" + fn)(ctypes.byref(args), ctypes.c_void_p(stream))
+    else:  # tensors on a device that is not current: the launchers key their per-device state on hipGetDevice()
+        with torch.cuda.device(dev):
+            if stream is None:
+                stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = getattr(L, "dig_" + fn)(ctypes.byref(args), ctypes.c_void_p(stream))
     if rc != 0:
         raise RuntimeError(f"dig_{fn} failed ({rc}): {L.dig_last_error().decode()}")
 

@@ -189,6 +189,8 @@ def mctformer_forward(m, img, n_layers=12, feat_diff=None):
     feat_diff (five [B,1024,h,w] guidance maps) also cam_diff, diff_cls, diff_pcls (mctformer.py:265-291,324-346)."""
     if not img.is_cuda:
         raise RuntimeError("dig_amd.MCTformerV2_DiG runs on the HIP device only (no CPU fallback)")
+    from .diffusion import _same_device
+    _same_device(m, img.device, "MCTformerV2_DiG")
     P = _pack(m)
     B, _, H, W = img.shape
     C, D, heads, ps = m.num_classes, m.embed_dim, m.num_heads, m.patch_embed.patch_size[0]

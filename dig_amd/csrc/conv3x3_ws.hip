@@ -53,12 +53,16 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 #define WS_STAGE_PRIO 2
 #endif
 
+#ifndef WS_TRACE_BLOCK
+#define WS_TRACE_BLOCK 0
+#endif
 #ifdef WS_TRACE
 // per-phase timestamps of block 0, kept in registers during the phase and written out after its barrier
-__device__ unsigned long long ws_trace[8 * 64 * 8];  // [wave][phase][start, role end, barrier end, stage: loads issued, E1, E2, -, -]
+__device__ unsigned long long ws_trace[8 * 64 * 8];
+__device__ unsigned long long ws_blk[256 * 2];  // per block: cycles from kernel entry to exit, realtime at entry  // [wave][phase][start, role end, barrier end, stage: loads issued, E1, E2, -, -]
 #define WS_STAMP(slot) ws_t[slot] = __builtin_amdgcn_s_memtime();
 #define WS_FLUSH()                                                                                  \
-    if (blockIdx.x == 0 && lane == 0 && ph + 1 < 64)                                                \
+    if (blockIdx.x == WS_TRACE_BLOCK && lane == 0 && ph + 1 < 64)                                                \
         for (int s_ = 0; s_ < 6; s_++) ws_trace[(wave * 64 + ph + 1) * 8 + s_] = ws_t[s_];
 #else
 #define WS_STAMP(slot)
@@ -339,6 +343,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
 
+#ifdef WS_TRACE
+    const unsigned long long ws_t_entry = __builtin_amdgcn_s_memtime();
+    const unsigned long long ws_rt_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     if (p.aff && tile_of(0) < p.ntiles && tg < 128) aff_l[tg] = p.aff[(size_t)(tile_of(0) / tiles_img) * 128 + tg];
     __syncthreads();  // weights, bias and the first affine are in LDS
     for (int ph = -1; ph <= 2 * K; ph++) {
@@ -430,6 +438,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         WS_STAMP(2)
         WS_FLUSH()
     }
+#ifdef WS_TRACE
+    if (tid == 0) {
+        ws_blk[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - ws_t_entry;
+        ws_blk[blockIdx.x * 2 + 1] = ws_rt_entry;
+    }
+#endif
 }
 
 }  // namespace
@@ -478,5 +492,8 @@ int conv3x3_ws64_launch(const dig_conv3x3_args* a, hipStream_t stream) {
 #ifdef WS_TRACE
 extern "C" int dig_debug_ws_trace(unsigned long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ws_trace), sizeof(unsigned long long) * 8 * 64 * 8);
+}
+extern "C" int dig_debug_ws_blk(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ws_blk), sizeof(unsigned long long) * 256 * 2);
 }
 #endif

@@ -366,6 +366,7 @@ extern "C" int dig_row_max(const dig_row_max_args* a, void* stream_) {
 extern "C" int dig_sched_axpby(const dig_sched_axpby_args* a, void* stream_) {
     STREAM;
     DIG_CHECK(a && a->x && a->y && a->t && a->sqrt_ac && a->sqrt_1mac && a->out, DIG_EINVAL, "sched_axpby: null pointer");
+    DIG_CHECK(a->B > 0 && a->HW > 0, DIG_EINVAL, "sched_axpby: bad shape B=%d HW=%d", a->B, a->HW);
     hipLaunchKernelGGL(sched_axpby_kernel, dim3(grid_for((size_t)a->B * 3 * a->HW, 256)), dim3(256), 0, stream, *a);
     DIG_LAUNCH_CHECK("sched_axpby");
     return DIG_OK;

@@ -392,11 +392,34 @@ def _time_embedding(u, P, t):
     return temb, ops.linear_rows(st, P["mlp_w"], bias=P["mlp_b"])  # [B, sum 2*C] fp32
 
 
+def _same_device(module, dev, what):
+    """Raise (before any kernel launch) unless every parameter and buffer of `module` lives on `dev`: the kernels take raw
+    pointers, so a CPU-resident or other-GPU weight would be a GPU fault, not an exception."""
+    for name, p in list(module.named_parameters()) + list(module.named_buffers()):
+        if p.device != dev:
+            raise RuntimeError(f"dig_amd.{what}: parameter {name!r} lives on {p.device} but the input on {dev}; "
+                               f"move the module with .to('{dev}') first (no CPU fallback)")
+
+
+def _check_t(t, num_timesteps, B):
+    """extract() in the reference (ddp.py:452-455) is a gather that raises on an out-of-range index; here the tables are
+    indexed by the kernels directly, so validate on the host."""
+    if t.dim() != 1 or t.shape[0] != B:
+        raise ValueError(f"t must have shape [{B}], got {tuple(t.shape)}")
+    if B and (int(t.min()) < 0 or int(t.max()) >= num_timesteps):
+        raise IndexError(f"timestep out of range: t must lie in [0, {num_timesteps}), got [{int(t.min())}, {int(t.max())}]")
+
+
 def _unet_forward(u, img, noise, t, sqrt_ac, sqrt_1mac, pre_scale, pre_shift, want_xt, debug=None):
     """Shared body of Unet.forward and GaussianDiffusion.p_losses.  img [B,3,H,W] fp32 NCHW.
     With noise=None the stem runs with (1, 0) coefficients, i.e. x_t = pre(img)."""
     if not img.is_cuda:
         raise RuntimeError("dig_amd.Unet runs on the HIP device only (no CPU fallback); move inputs with .cuda()")
+    _same_device(u, img.device, "Unet")
+    for name, buf in (("noise", noise), ("sqrt_alphas_cumprod", sqrt_ac), ("sqrt_one_minus_alphas_cumprod", sqrt_1mac)):
+        if buf is not None and buf.device != img.device:
+            raise RuntimeError(f"dig_amd.Unet: {name} lives on {buf.device} but the input on {img.device}; move the "
+                               "GaussianDiffusion module with .to(device) first")
     B, Cin, H, W = img.shape
     f = u.downsample_factor
     assert H % f == 0 and W % f == 0, f"your input dimensions {(H, W)} need to be divisible by {f}, given the unet"
@@ -527,9 +550,15 @@ class GaussianDiffusion(nn.Module):
         return (t + 1) * 0.5 if self.auto_normalize else t
 
     def _axpby(self, x, y, t, sign, post_scale=(1.0,) * 3, post_shift=(0.0,) * 3):
-        assert x.is_cuda, "dig_amd.GaussianDiffusion runs on the HIP device only"
+        if not x.is_cuda:
+            raise RuntimeError("dig_amd.GaussianDiffusion runs on the HIP device only (no CPU fallback)")
         B, C, H, W = x.shape
-        assert C == 3
+        assert C == 3 and B > 0 and H * W > 0
+        if self.sqrt_alphas_cumprod.device != x.device or y.device != x.device:
+            raise RuntimeError(f"dig_amd.GaussianDiffusion: schedule buffers on {self.sqrt_alphas_cumprod.device}, operands on "
+                               f"{x.device} / {y.device}; move the module with .to(device) first")
+        t = t.to(x.device)
+        _check_t(t, self.num_timesteps, B)
         out = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
         call("sched_axpby", x=x.contiguous().float(), y=y.contiguous().float(), t=t.to(torch.long).contiguous(),
              sqrt_ac=self.sqrt_alphas_cumprod, sqrt_1mac=self.sqrt_one_minus_alphas_cumprod, out=out,
@@ -557,6 +586,8 @@ class GaussianDiffusion(nn.Module):
         ons = offset_noise_strength if offset_noise_strength is not None else self.offset_noise_strength
         if ons > 0.:
             noise = noise + ons * torch.randn(x_start.shape[:2], device=x_start.device)[:, :, None, None]
+        if x_start.is_cuda:
+            _check_t(t, self.num_timesteps, x_start.shape[0])
         pred, feats, x_t = _unet_forward(self.model, x_start, noise, t, self.sqrt_alphas_cumprod,
                                          self.sqrt_one_minus_alphas_cumprod, pre_scale, pre_shift, want_xt=True)
         return x_t, pred, feats

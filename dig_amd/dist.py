@@ -38,10 +38,22 @@ def run_sharded(fn, *batched_inputs, group=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = batched_inputs[0].shape[0]
+    assert n > 0, "run_sharded needs at least one item"
     lo, hi = shard_bounds(n, world, rank)
-    outs = fn(*[x[lo:hi] for x in batched_inputs])
-    single = torch.is_tensor(outs)
-    outs = [outs] if single else list(outs)
+    outs, single = None, None
+    if hi > lo:  # the kernels reject B == 0: a rank whose shard is empty (n < world) skips the compute
+        outs = fn(*[x[lo:hi] for x in batched_inputs])
+        single = torch.is_tensor(outs)
+        outs = [outs] if single else list(outs)
+    if n < world:
+        # ranks with an empty shard learn the output shapes from rank 0 (which always owns item 0) and contribute a
+        # zero-length slice to the gather
+        spec = [(single, [(tuple(o.shape[1:]), o.dtype) for o in outs])] if rank == 0 else [None]
+        dist.broadcast_object_list(spec, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        single, shapes = spec[0]
+        if outs is None:
+            dev = batched_inputs[0].device
+            outs = [torch.empty((0,) + shp, dtype=dt, device=dev) for shp, dt in shapes]
     res = [all_gather_batch(o, n, group) for o in outs]
     return res[0] if single else res
 
@@ -61,7 +73,9 @@ class PipelinedGather:
         self.count = 0
 
     def submit(self, local):
-        """Queue the gather of `local` ([b, ...], equal b on every rank); returns the PREVIOUS step's gathered tensor (or None)."""
+        """Queue the gather of `local` ([b, ...], equal b on every rank); returns the PREVIOUS step's gathered tensor (or None).
+        The returned tensor is one of the two internal buffers: it stays valid until the submit() AFTER the next one
+        overwrites it (two steps) - consume it within that window or .clone() it."""
         if not self.collective:
             prev, self.pending = (self.pending[1] if self.pending else None), (None, local, None)
             return prev

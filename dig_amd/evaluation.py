@@ -14,13 +14,28 @@ CATEGORIES = ['background', 'aeroplane', 'bicycle', 'bird', 'boat', 'bottle', 'b
               'diningtable', 'dog', 'horse', 'motorbike', 'person', 'pottedplant', 'sheep', 'sofa', 'train', 'tvmonitor']
 
 
-def save_cam_dict(path, cam_dict):
-    """model.py:489-492: np.save(os.path.join(dict_dir, name + '.npy'), cam_dict)."""
-    np.save(path, {int(k): np.asarray(v, np.float32) for k, v in cam_dict.items()})
+def save_cam_dict(path, cam_dict, reference_format=False):
+    """Write {class index -> float32 [H, W]}.  Default: an .npz archive of plain arrays (one entry per class index), which
+    loads without executing anything.  reference_format=True writes what model.py:489-492 writes - np.save of the dict
+    itself, i.e. a pickle inside the .npy - for interchange with the reference's evaluation.py."""
+    d = {int(k): np.asarray(v, np.float32) for k, v in cam_dict.items()}
+    if reference_format:
+        np.save(path, d)
+    else:
+        np.savez(path if str(path).endswith(".npz") else str(path) + ".npz", **{str(k): v for k, v in d.items()})
 
 
-def load_cam_dict(path):
-    """evaluation.py:44: np.load(file, allow_pickle=True).item() - only for files written by save_cam_dict."""
+def load_cam_dict(path, reference_format=False):
+    """Read a cam_dict.  .npz files (save_cam_dict's default) are read with allow_pickle=False.  The reference's .npy files
+    (evaluation.py:44: np.load(file, allow_pickle=True).item()) hold a pickled dict; unpickling executes code from the file,
+    so that loader runs only when the caller opts in with reference_format=True - use it on files you wrote yourself."""
+    path = str(path)
+    if path.endswith(".npz"):
+        with np.load(path, allow_pickle=False) as z:
+            return {int(k): z[k] for k in z.files}
+    if not reference_format:
+        raise ValueError(f"{path}: a reference-format .npy cam_dict is a pickle; pass reference_format=True to load it "
+                         "(only for files you trust), or save with save_cam_dict(..., reference_format=False)")
     return np.load(path, allow_pickle=True).item()
 
 
@@ -59,16 +74,19 @@ def metrics_from_counts(P, T, TP, categories=None):
     return out
 
 
-def do_python_eval(predict_folder, gt_folder, name_list, num_cls=21, task="cam", threshold=0.45, device="cuda"):
+def do_python_eval(predict_folder, gt_folder, name_list, num_cls=21, task="cam", threshold=0.45, device="cuda",
+                   reference_format=False):
     """Same arguments and result dict as evaluation.py:29-129 for task 'cam' and 'png'; files are read on the host, the
-    argmax and the counting run on the device."""
+    argmax and the counting run on the device.  CAM dicts are looked up as <name>.npz first; the reference's pickled
+    <name>.npy is read only with reference_format=True (see load_cam_dict)."""
     from PIL import Image
     assert task in ("cam", "png"), "only the CAM-dict and PNG tasks are on this path"
     ctr = SegCounter(num_cls, device)
     for name in name_list:
         gt = torch.from_numpy(np.array(Image.open(os.path.join(gt_folder, "%s.png" % name))).astype(np.uint8)).to(device)
         if task == "cam":
-            d = load_cam_dict(os.path.join(predict_folder, "%s.npy" % name))
+            npz = os.path.join(predict_folder, "%s.npz" % name)
+            d = load_cam_dict(npz) if os.path.exists(npz) else load_cam_dict(os.path.join(predict_folder, "%s.npy" % name), reference_format)
             h, w = next(iter(d.values())).shape
             camt = torch.zeros(1, num_cls - 1, h, w, dtype=torch.float32, device=device)
             lab = torch.zeros(1, num_cls - 1, dtype=torch.float32, device=device)

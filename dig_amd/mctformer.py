@@ -70,12 +70,15 @@ class _LFCA(_Holder):
 
 
 class MCTformerV2_DiG(nn.Module):
-    """`lfca=False` (default) omits the LFCA0/LFCA1/diff_head_p parameters (191 M; the consumer of the guidance maps,
-    used by the training step - load reference checkpoints with strict=False in that case); `lfca=True` creates them
-    under the reference's names and enables forward(x, feat_diff=[5 x [B,1024,h,w]]) in eval mode."""
+    """Same parameter tree as the reference (mctformer.py:171-192): `lfca=True` (default) creates LFCA0 / LFCA1 /
+    diff_head_p under the reference's names, so `load_state_dict(torch.load('{epo:03d}net_trm.pth'))` (model.py:214-218)
+    works strictly, and forward(x, feat_diff=[5 x [B,1024,h,w]]) runs the LFCA consumer in eval mode.  `lfca=False` is an
+    explicit opt-out that saves the 191 M LFCA parameters for CAM-only inference (then load checkpoints with strict=False).
+    Stochastic depth / dropout (drop_path_rate, drop_rate) are training features and are not implemented: forward() in
+    training mode raises instead of silently running without them."""
 
     def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=20, embed_dim=384, depth=12, num_heads=6,
-                 mlp_ratio=4., lfca=False, **_ignored):
+                 mlp_ratio=4., lfca=True, drop_rate=0., drop_path_rate=0., **_ignored):
         super().__init__()
         self.num_classes, self.embed_dim, self.num_heads, self.depth = num_classes, embed_dim, num_heads, depth
         self.patch_embed = _PatchEmbed(patch_size, in_chans, embed_dim)
@@ -92,17 +95,19 @@ class MCTformerV2_DiG(nn.Module):
             # the reference hard-codes 20 output maps here whatever num_classes is (mctformer.py:189)
             self.diff_head_p = nn.Sequential(nn.Conv2d(self.D_f, self.D_f, 3, 1, 1), nn.ReLU(inplace=True), nn.Conv2d(self.D_f, 20, 1, 1, 0))
         self.has_lfca = bool(lfca)
+        self.drop_rate, self.drop_path_rate = float(drop_rate or 0.), float(drop_path_rate or 0.)
         self.lfca_dtype = torch.float32  # storage type of the LFCA convolutions / wide GEMMs: float32 (parity) or bfloat16 (fast)
         self._packed = None
         self._packed_lfca = None
 
     def forward(self, x, feat_diff=None, return_att=False, n_layers=12, detach=True):
         from . import cam
-        if feat_diff is not None:
-            if not self.has_lfca:
-                raise RuntimeError("this model was built with lfca=False: no LFCA0/LFCA1/diff_head_p parameters")
-            if self.training:
-                raise NotImplementedError("the LFCA branch is forward-only here (DropPath 0.1 is a training feature); call .eval()")
+        if self.training and (self.drop_path_rate > 0 or self.drop_rate > 0 or feat_diff is not None):
+            # the reference trains with DropPath(drop_path_rate) in every block and DropPath(0.1) inside LFCA
+            # (vision_transformer.py:184-186, mctformer.py:93,163-164); this build is forward-only
+            raise NotImplementedError("dig_amd.MCTformerV2_DiG is forward-only (no DropPath / dropout): call .eval() first")
+        if feat_diff is not None and not self.has_lfca:
+            raise RuntimeError("this model was built with lfca=False: no LFCA0/LFCA1/diff_head_p parameters")
         outs = cam.mctformer_forward(self, x, n_layers, feat_diff=feat_diff)
         return outs["rcams"] if return_att else outs
 
@@ -119,7 +124,7 @@ MCTformerV2_DiG.set_lfca_dtype = _set_lfca_dtype
 def deit_small_MCTformerV2_DiG(pretrained=False, **kwargs):
     if pretrained:
         raise RuntimeError("pretrained weights are downloaded by the reference; unavailable offline")
-    kwargs.pop("drop_rate", None), kwargs.pop("drop_path_rate", None), kwargs.pop("drop_block_rate", None)
+    kwargs.pop("drop_block_rate", None)
     return MCTformerV2_DiG(patch_size=16, embed_dim=384, depth=12, num_heads=6, mlp_ratio=4, **kwargs)
 
 

@@ -10,6 +10,7 @@ oracle/ref_import.py with off-path dependency stubs).  For every case it
 
 Usage:  python oracle/gen_golden.py            (rewrites tests/golden/)
         python oracle/gen_golden.py lfca       (only the LFCA cases; merges into MANIFEST.json)
+        python oracle/gen_golden.py keys       (only tests/golden/state_dict_keys.json)
 """
 import json
 import os
@@ -286,6 +287,20 @@ def case_eval(ev):
     save("eval_cam", **arrays)
 
 
+def case_state_dict_keys(ddp, mct):
+    """Full {key: shape} tables of the two reference modules whose checkpoints the product must load unchanged
+    (model.py:140-142 diffusion.load_state_dict(...['model']); model.py:214-218 net_trm.load_state_dict)."""
+    unet = ddp.Unet(dim=64, dim_mults=(1, 2, 4, 8), flash_attn=True)
+    gd = ddp.GaussianDiffusion(unet, image_size=224, timesteps=1000, sampling_timesteps=150)
+    tables = {"GaussianDiffusion(Unet(dim=64,dim_mults=(1,2,4,8)))": {k: list(v.shape) for k, v in gd.state_dict().items()}}
+    for C in (20, 80):
+        m = mct.deit_small_MCTformerV2_DiG(num_classes=C)
+        tables[f"deit_small_MCTformerV2_DiG(num_classes={C})"] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    with open(os.path.join(GOLD, "state_dict_keys.json"), "w") as f:
+        json.dump(tables, f, indent=0, sort_keys=True)
+    print("[state_dict_keys] " + "  ".join(f"{k}: {len(v)} entries" for k, v in tables.items()))
+
+
 def _merge_manifest():
     mp = os.path.join(GOLD, "MANIFEST.json")
     with open(mp) as f:
@@ -302,6 +317,9 @@ def main():
         case_lfca(mct, "lfca224_c20", 20, 224, 224, 14, 14)
         case_lfca(mct, "lfca224_c20_maps16", 20, 224, 224, 16, 16)
         _merge_manifest()
+        return
+    if sys.argv[1:] == ["keys"]:
+        case_state_dict_keys(ref_import.load_ddp(), mct)
         return
     if sys.argv[1:] == ["eval"]:
         case_eval(ref_import.load_evaluation())
@@ -320,6 +338,7 @@ def main():
     case_lfca(mct, "lfca224_c20", 20, 224, 224, 14, 14)
     case_lfca(mct, "lfca224_c20_maps16", 20, 224, 224, 16, 16)  # guidance maps from a 256x256 diffusion input: bilinear 14 -> 16
     case_eval(ref_import.load_evaluation())
+    case_state_dict_keys(ddp, mct)
     with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
         json.dump({"generator": "oracle/gen_golden.py", "torch": torch.__version__,
                    "what": "max-abs |reference - oracle| per output, fp32 CPU", "cases": MANIFEST,

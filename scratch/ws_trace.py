@@ -20,3 +20,12 @@ for ph in range(0, 12):
         stage = (ph - 1 - (w >> 2)) & 1
         row.append(f"w{w}: {a:7d} +{b-a:6d} +{c-b:6d}" + (f" [gl {s3-a:5d} E1 {s4-s3:5d} E2 {s5-s4:5d} ls {b-s5:5d}]" if stage else " " * 41))
     print(f"ph{ph-1:3d} ", " | ".join(row))
+
+blk = (ctypes.c_ulonglong * 512)()
+print("rc", L.dig_debug_ws_blk(blk))
+cyc = [blk[2 * i] for i in range(256)]
+rt0 = min(blk[2 * i + 1] for i in range(256))
+print("block cycles: min %d median %d max %d" % (min(cyc), sorted(cyc)[128], max(cyc)))
+print("entry skew (100MHz ticks): max", max(blk[2 * i + 1] - rt0 for i in range(256)))
+for i in range(0, 256, 8):
+    print(i, " ".join("%6d" % c for c in cyc[i:i + 8]))

@@ -22,8 +22,9 @@ def T(a):
 
 
 def make_mct(C):
-    m = create_model("deit_small_MCTformerV2_DiG", pretrained=False, num_classes=C, drop_rate=0.0, drop_path_rate=0.1, drop_block_rate=None)
-    synth.fill_state_dict(m, seed=0, skip_prefixes=("LFCA", "diff_head_p", "norm."))
+    # the reference call site (model.py:117-124) + the explicit CAM-only opt-out that leaves the 191 M LFCA parameters out
+    m = create_model("deit_small_MCTformerV2_DiG", pretrained=False, num_classes=C, drop_rate=0.0, drop_path_rate=0.1, drop_block_rate=None, lfca=False)
+    synth.fill_state_dict(m, seed=0, skip_prefixes=("norm.",))
     return m.to(DEV).eval()
 
 
@@ -183,7 +184,16 @@ def test_miou_evaluation_vs_oracle(tmp_path):
             gt[d[k] > 0.5] = k + 1
         gt[rng.rand(H, W) < 0.05] = 255
         name = f"img{n}"
-        E.save_cam_dict(str(tmp_path / f"{name}.npy"), d)
+        # default format: .npz of plain arrays; image 0 also in the reference's pickled .npy format (read only on opt-in)
+        E.save_cam_dict(str(tmp_path / f"{name}.npz"), d)
+        if n == 0:
+            E.save_cam_dict(str(tmp_path / "ref0.npy"), d, reference_format=True)
+            with pytest.raises(ValueError, match="reference_format"):
+                E.load_cam_dict(str(tmp_path / "ref0.npy"))
+            back = E.load_cam_dict(str(tmp_path / "ref0.npy"), reference_format=True)
+            assert sorted(back) == sorted(d) and all(np.array_equal(back[k], d[k]) for k in d)
+            again = E.load_cam_dict(str(tmp_path / f"{name}.npz"))
+            assert sorted(again) == sorted(d) and all(np.array_equal(again[k], d[k]) for k in d)
         Image.fromarray(gt).save(str(tmp_path / f"{name}.png"))
         names.append(name), dicts.append(d), gts.append(gt)
     for thr in (0.35, 0.5):

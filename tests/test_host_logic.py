@@ -2,6 +2,7 @@
 calls without a GPU), argument structs mirror the header, product modules keep the reference's state_dict keys and
 refuse to run off-device (no CPU fallback), synthetic generators are deterministic, sharding + all-gather (gloo, 2 ranks)."""
 import ctypes
+import json
 import os
 import re
 import subprocess
@@ -58,14 +59,95 @@ def test_state_dict_keys_and_no_cpu_fallback():
     assert abs(float(gd.sqrt_alphas_cumprod[100]) - 0.97979611) < 1e-7
     with pytest.raises(RuntimeError, match="HIP device only"):
         gd.p_losses(torch.zeros(1, 3, 32, 32), torch.zeros(1, dtype=torch.long), noise=torch.zeros(1, 3, 32, 32))
-    m = create_model("deit_small_MCTformerV2_DiG", pretrained=False, num_classes=20, drop_rate=0.0, drop_path_rate=0.1, drop_block_rate=None)
-    keys = set(m.state_dict())
-    assert {"cls_token", "pos_embed", "patch_embed.proj.weight", "blocks.11.mlp.fc2.bias", "blocks.0.attn.qkv.bias", "norm.weight", "head.weight"} <= keys
-    assert m.state_dict()["pos_embed"].shape == (1, 216, 384)
-    with pytest.raises(RuntimeError, match="HIP device only"):
-        m(torch.zeros(1, 3, 224, 224), return_att=True)
     with pytest.raises(NotImplementedError):
         Unet(dim=64, self_condition=True)
+    # the reference's own {key: shape} table (tests/golden/state_dict_keys.json, written by oracle/gen_golden.py from the
+    # imported reference modules): set-equality, so model.py:140-142's strict load_state_dict works unchanged
+    with open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json")) as f:
+        tables = json.load(f)
+    ref = tables["GaussianDiffusion(Unet(dim=64,dim_mults=(1,2,4,8)))"]
+    assert {k: list(v.shape) for k, v in sd.items()} == ref
+
+
+@pytest.mark.parametrize("C", [20, 80])
+def test_mctformer_state_dict_matches_reference_call_site(C):
+    """model.py:117-124 (create_model with the reference's keywords, nothing else) then model.py:214-218 (strict load):
+    the default build carries LFCA0 / LFCA1 / diff_head_p, key- and shape-identical to the reference's table."""
+    with open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json")) as f:
+        ref = json.load(f)[f"deit_small_MCTformerV2_DiG(num_classes={C})"]
+    m = create_model("deit_small_MCTformerV2_DiG", pretrained=False, num_classes=C, drop_rate=0.0, drop_path_rate=0.1, drop_block_rate=None)
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == ref
+    m.load_state_dict({k: torch.zeros(v) for k, v in ref.items()}, strict=True)
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        m.eval()(torch.zeros(1, 3, 224, 224), return_att=True)
+    with pytest.raises(NotImplementedError, match="forward-only"):
+        m.train()(torch.zeros(1, 3, 224, 224))  # the reference's update() runs DropPath 0.1 here: refuse instead of diverging silently
+    small = create_model("deit_small_MCTformerV2_DiG", pretrained=False, num_classes=C, lfca=False)  # explicit CAM-only opt-out
+    assert set(small.state_dict()) == {k for k in ref if not k.startswith(("LFCA", "diff_head_p"))}
+
+
+class _FakeDeviceTensor(torch.Tensor):
+    """A CPU tensor that claims to live on a HIP device: lets the CPU tier drive the product's guards up to (not into) a launch."""
+
+    @staticmethod
+    def __new__(cls, t):
+        return torch.Tensor._make_subclass(cls, t)
+
+    @property
+    def is_cuda(self):
+        return True
+
+    @property
+    def device(self):
+        return torch.device("cuda", 0)
+
+
+def test_cpu_resident_module_and_bad_timesteps_raise_before_any_launch(monkeypatch):
+    """the guards must look at the parameters/buffers too, not only at the input, and t must be range-checked on
+    the host (the kernels index the schedule tables with it).  No GPU here: any attempt to launch would hit _lib.call."""
+    from dig_amd import _lib as L, diffusion as D
+
+    def no_launch(fn, **kw):
+        raise AssertionError(f"dig_{fn} would have been launched")
+
+    monkeypatch.setattr(D, "call", no_launch)
+    u = Unet(dim=16, dim_mults=(1, 2, 4, 8), flash_attn=True)
+    gd = GaussianDiffusion(u, image_size=32, timesteps=1000, sampling_timesteps=150).eval()
+    x = _FakeDeviceTensor(torch.zeros(2, 3, 32, 32))
+    t = torch.zeros(2, dtype=torch.long)
+    with pytest.raises(RuntimeError, match=r"lives on cpu but the input on cuda:0"):
+        gd.p_losses(x, t, noise=x)
+    with pytest.raises(RuntimeError, match=r"lives on cpu but the input on cuda:0"):
+        u(x, t)
+    with pytest.raises(RuntimeError, match="schedule buffers on cpu"):
+        gd.q_sample(x, t, noise=x)
+    with pytest.raises(IndexError, match="timestep out of range"):
+        gd.p_losses(x, torch.tensor([0, 1000]), noise=x)
+    with pytest.raises(IndexError, match="timestep out of range"):
+        gd.p_losses(x, torch.tensor([-1, 5]), noise=x)
+    m = create_model("deit_small_MCTformerV2_DiG", pretrained=False, num_classes=20, lfca=False).eval()
+    with pytest.raises(RuntimeError, match=r"lives on cpu but the input on cuda:0"):
+        m(_FakeDeviceTensor(torch.zeros(1, 3, 224, 224)), return_att=True)
+    # the ctypes layer itself refuses host tensors (no pointer of a CPU tensor ever reaches a kernel)
+    with pytest.raises(RuntimeError, match="HIP-device pointers only"):
+        L.call("rmsnorm", x=torch.zeros(4, 8), g=torch.zeros(8), res=None, out=torch.zeros(4, 8), rows=4, C=8, dtype=1)
+    a = L.STRUCTS["dig_sched_axpby_args"]()
+    for f in ("x", "y", "t", "sqrt_ac", "sqrt_1mac", "out"):
+        setattr(a, f, 16)
+    assert L.lib().dig_sched_axpby(ctypes.byref(a), None) == -1 and b"bad shape" in L.lib().dig_last_error()
+
+
+def test_cam_dict_formats(tmp_path):
+    import numpy as np
+    from dig_amd import evaluation as E
+    d = {3: np.arange(12, dtype=np.float32).reshape(3, 4), 17: np.ones((3, 4), np.float32)}
+    E.save_cam_dict(str(tmp_path / "a.npz"), d)
+    back = E.load_cam_dict(str(tmp_path / "a.npz"))
+    assert sorted(back) == [3, 17] and np.array_equal(back[3], d[3])
+    E.save_cam_dict(str(tmp_path / "b.npy"), d, reference_format=True)  # model.py:489-492's format: a pickled dict
+    with pytest.raises(ValueError, match="reference_format"):
+        E.load_cam_dict(str(tmp_path / "b.npy"))
+    assert np.array_equal(E.load_cam_dict(str(tmp_path / "b.npy"), reference_format=True)[17], d[17])
 
 
 def test_synth_is_deterministic_and_keyed():
@@ -110,7 +192,7 @@ print("ok", rank)
 """
 
 
-@pytest.mark.parametrize("n", [8, 7])
+@pytest.mark.parametrize("n", [8, 7, 1])
 def test_sharded_all_gather_gloo_world2(tmp_path, n):
     script = tmp_path / "w.py"
     script.write_text(_WORKER)
