@@ -100,6 +100,18 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
 
+// q_sample / predict_start_from_v element (ddp.py:857-860, 630-634): two rounded products and a rounded sum, exactly the
+// reference's tensor expression.  The files are built with -ffp-contract=fast, under which the backend fuses a product
+// into the sum wherever it likes (a `#pragma clang fp contract(off)` does not stop it): every inlined copy could fuse a
+// different product, and a halo pixel computed by one tile would round differently from the same pixel computed by the
+// tile that owns it.  The empty asm statements make both products opaque, so nothing can be fused.
+__device__ __forceinline__ float axpby_rn(float ca, float x, float cs, float y) {
+    float p = ca * x;
+    float q = cs * y;
+    asm volatile("" : "+v"(p), "+v"(q));
+    return p + q;
+}
+
 // x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (1 ulp): no IEEE division sequence in the conv loader's prologue
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }

@@ -103,6 +103,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     const int K = (p.ntiles + 2 * (int)gridDim.x - 1) / (2 * (int)gridDim.x);
     auto tile_of = [&](int k) { return (k * (int)gridDim.x + (int)blockIdx.x) * 2 + grp; };
+    // linear tile index -> (image, tile inside the image).  A block's tiles are 2 * gridDim.x apart, usually a whole number
+    // of images, so without the rotation a block would sit on ONE tile position for its whole life and the blocks on the
+    // image border (clamped addressing, zero fill: ~15 % more cycles per tile) would finish last.  Rotating the tile index
+    // by an image-dependent offset gives every block the same mix; neighbouring blocks still work on neighbouring tiles.
+    auto decode = [&](int t, int& b, int& tl) {
+        b = t / tiles_img;
+        tl = t - b * tiles_img;
+#ifndef WS_NO_ROTATE
+        tl = (int)(((unsigned)tl + (unsigned)b * 37u) % (unsigned)tiles_img);
+#endif
+    };
 
     // ---- staging geometry, fixed per thread: vector i covers halo pixel hp_i (pixel rows 64*wg..64*wg+63 are the wave's
     // own 8 KB slice, 256.. the shared tail) and channels 8*sv..8*sv+7.  goff: element offset of its source from the
@@ -120,7 +131,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 
     auto gaddr = [&](int t, unsigned (&off)[NVEC], const bf16*& base, unsigned& hok, bool& interior) {
-        const int b = t / tiles_img, tl = t - b * tiles_img;
+        int b, tl;
+        decode(t, b, tl);
         const int ty0 = (tl / p.tiles_x) * 16, tx0 = (tl % p.tiles_x) * 16;
         const bf16* img = p.in + (size_t)b * p.bstride;
         // one load sequence for both cases (no control flow around the loads): a scalar base + 32-bit element offsets
@@ -149,42 +161,41 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
     };
-    auto lstore = [&](const bf16x8 (&pre)[NVEC], unsigned hok, bool all) {
-        const bool pro = p.aff != nullptr;
-        // GroupNorm-apply + SiLU on packed pairs: v = a x + b, silu = v / (1 + 2^(-v log2 e)); per element 3.5 VALU
-        // (v_pk_*) + the two transcendentals.  na/nb = -a log2 e, -b log2 e.
-        f32x2 pa[4], pb[4], na[4], nb[4];
-        if (pro) {
+    // GroupNorm-apply + SiLU prologue: v = a x + b, silu = v / (1 + 2^(-v log2 e)).  Plain scalar
+    // f32 VALU on purpose: gfx950's SIMD-32 gains nothing from v_pk_*_f32 and pays extra issue cycles for them beside
+    // MFMAs (MI355X_MICROARCH.md, cycle constants) - the file is built with -fno-slp-vectorize so the compiler keeps it so.
+    struct Aff {
+        float pa[8], pb[8];
+    };
+    auto lstore_setup = [&](Aff& A) {
+        if (p.aff != nullptr) {
             const f32x4* af = reinterpret_cast<const f32x4*>(aff_l + sv * 16);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const f32x4 v = af[j];  // (a, b) of channels 2j, 2j+1
-                pa[j] = f32x2{v[0], v[2]};
-                pb[j] = f32x2{v[1], v[3]};
-                na[j] = pa[j] * (-1.4426950408889634f);
-                nb[j] = pb[j] * (-1.4426950408889634f);
+                A.pa[2 * j] = v[0]; A.pb[2 * j] = v[1]; A.pa[2 * j + 1] = v[2]; A.pb[2 * j + 1] = v[3];
             }
         }
+    };
+    // one 16-byte halo vector: prologue, zero fill outside the image, swizzled LDS store
+    auto lstore_vec = [&](const Aff& A, const bf16x8& prev, int i, int lo, unsigned hok, bool all) {
+        if (i < 10 || lo >= 0) {
+            i32x4 w = __builtin_bit_cast(i32x4, prev);
+            if (p.aff != nullptr) {
 #pragma unroll
-        for (int i = 0; i < NVEC; i++) {
-            if (i < 10 || loff[i] >= 0) {
-                i32x4 w = __builtin_bit_cast(i32x4, pre[i]);
-                if (pro) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const f32x2 x = f32x2{__builtin_bit_cast(float, w[j] << 16), __builtin_bit_cast(float, w[j] & (int)0xffff0000)};
-                        const f32x2 t = na[j] * x + nb[j];
-                        const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.0f;
-                        const f32x2 rc = f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-                        const f32x2 o = (pa[j] * x + pb[j]) * rc;
-                        w[j] = __builtin_bit_cast(int, bf16x2{(bf16)o[0], (bf16)o[1]});
-                    }
+                for (int j = 0; j < 4; j++) {
+                    const float x0 = __builtin_bit_cast(float, w[j] << 16), x1 = __builtin_bit_cast(float, w[j] & (int)0xffff0000);
+                    const float v0 = fmaf(A.pa[2 * j], x0, A.pb[2 * j]), v1 = fmaf(A.pa[2 * j + 1], x1, A.pb[2 * j + 1]);
+                    const float d0 = __builtin_amdgcn_exp2f(v0 * -1.4426950408889634f) + 1.0f;
+                    const float d1 = __builtin_amdgcn_exp2f(v1 * -1.4426950408889634f) + 1.0f;
+                    const float o0 = v0 * __builtin_amdgcn_rcpf(d0), o1 = v1 * __builtin_amdgcn_rcpf(d1);
+                    w[j] = __builtin_bit_cast(int, bf16x2{(bf16)o0, (bf16)o1});
                 }
-                if (!all) {  // scalar branch: border tiles only
-                    if (!(hok & (1u << i))) w = i32x4{0, 0, 0, 0};
-                }
-                *reinterpret_cast<i32x4*>(Hl + loff[i]) = w;
             }
+            if (!all) {  // scalar branch: border tiles only
+                if (!(hok & (1u << i))) w = i32x4{0, 0, 0, 0};
+            }
+            *reinterpret_cast<i32x4*>(Hl + lo) = w;
         }
     };
 
@@ -212,7 +223,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // 36 steps (tap, ks) of 4 MFMAs.  hipcc sinks plain LDS loads down to their first use (one step of latency
         // exposed per step), so the fragment reads are inline-asm ds_read_b128 issued PF steps ahead into a register
         // ring, with counted lgkmcnt waits that carry the ring registers as operands (the MFMAs depend on the wait).
-        constexpr int PF = 2, NST = 36;
+#ifndef WS_PF
+#define WS_PF 2
+#endif
+        constexpr int PF = WS_PF, NST = 36;
         i32x4 fa[PF + 1][2], fb[PF + 1][2];
         const unsigned hbase = lds_addr(Hl), wbase = lds_addr(Wl);
         unsigned haddr[3][4], waddr[2][4];  // halo [kx][ks] (tap row, mr: immediates); weights [taps 0-4 | 5-8][ks]
@@ -253,6 +267,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last MFMA retired before the accumulators are read (see conv3x3.hip)
         __builtin_amdgcn_sched_barrier(0);
+#if defined(WS_NO_E1) || defined(WS_NO_STAGE)  // ablation builds: keep the MFMAs alive although nobody reads their result
+        asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]));
+#endif
     };
 
     // ---- epilogue of the finished tile.  E1: accumulators -> bf16 -> the wave's slice + per-lane GroupNorm partials
@@ -288,7 +305,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
     auto epilogue_store = [&](int t, const bf16x8 (&od)[8], int i0, int i1) {
-        const int b = t / tiles_img, tl = t - b * tiles_img;
+        int b, tl;
+        decode(t, b, tl);
         const int ty0 = (tl / p.tiles_x) * 16, tx0 = (tl % p.tiles_x) * 16;
         bf16* outw = p.out + (((size_t)b * p.H + ty0 + wg * 4) * p.W + tx0) * 64;  // scalar
         const unsigned lo = (unsigned)(lq * 64 + sv * 8);
@@ -296,7 +314,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int i = i0; i < i1; i++) *reinterpret_cast<bf16x8*>(outw + (size_t)(((i >> 1) * p.W + (i & 1) * 8) * 64) + lo) = od[i];
     };
     auto epilogue_stats = [&](int t, const float (&st)[16]) {
-        const int b = t / tiles_img, tl = t - b * tiles_img;
+        int b, tl;
+        decode(t, b, tl);
         {
         if (p.stats) {
             // 16 per-lane partials -> wave totals with a halving butterfly: after the steps on lane bits 5,4,3,2 lane l
@@ -389,33 +408,67 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 WS_LOADS(0, 4)
                 __builtin_amdgcn_sched_barrier(0);
                 WS_STAMP(3)
+#ifndef WS_NO_E1
                 epilogue_regs(st, 0);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 WS_LOADS(4, 8)
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef WS_NO_E1
                 epilogue_regs(st, 1);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 WS_LOADS(8, NVEC)
                 __builtin_amdgcn_sched_barrier(0);
                 WS_STAMP(4)
                 epilogue_read(od);
                 __builtin_amdgcn_sched_barrier(0);
+                // The output stores and the prologue + LDS store of the prefetched halo are interleaved, one 16-byte vector
+                // each: a store that finds the CU's memory queue full blocks the wave for ~270 cycles, which is exactly the
+                // VALU time of one vector's GroupNorm-apply + SiLU - issued back to back (stores, then the prologue) the two
+                // costs add up; alternated, they overlap.  od[] is complete in registers before the first vector
+                // overwrites the wave's slice.
+                Aff A;
+                lstore_setup(A);
+                __builtin_amdgcn_sched_barrier(0);
+#ifndef WS_NO_LSTORE
+#define WS_LS(i) lstore_vec(A, pre[i], i, loff[i], hok, interior); __builtin_amdgcn_sched_barrier(0);
+#else
+#define WS_LS(i)
+#endif
+#ifdef WS_NO_E2
+                if constexpr (false) {
+#else
                 if constexpr (fin) {
-                    epilogue_store(tk, od, 0, 4);
-                    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        epilogue_store(tk, od, i, i + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        WS_LS(i)
+                    }
                     epilogue_stats(tk, st);
                     __builtin_amdgcn_sched_barrier(0);
-                    epilogue_store(tk, od, 4, 8);
-                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 4; i < 8; i++) {
+                        epilogue_store(tk, od, i, i + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        WS_LS(i)
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) { WS_LS(i) }
                 }
                 WS_STAMP(5)
-#ifndef WS_NO_LSTORE
-                lstore(pre, hok, interior);
-#endif
+#pragma unroll
+                for (int i = 8; i < NVEC; i++) { WS_LS(i) }
+#undef WS_LS
 #undef WS_LOADS
             };
+#ifndef WS_NO_STAGE
             if (fin) stage_body(std::true_type{});
             else stage_body(std::false_type{});
+#endif
         } else {
             // compute role (unconditional: a group without a tile multiplies stale LDS contents and nobody stores the result);
             // the GroupNorm affine of the tile staged NEXT phase travels global -> register -> LDS around it

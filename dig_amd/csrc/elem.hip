@@ -205,7 +205,8 @@ __global__ void sched_axpby_kernel(dig_sched_axpby_args a) {
         const int b = (int)(i / ((size_t)3 * a.HW));
         const int c = (int)((i / a.HW) % 3);
         const long long t = a.t[b];
-        const float v = a.sqrt_ac[t] * a.x[i] + a.sign * a.sqrt_1mac[t] * a.y[i];
+        // two rounded products and a rounded sum, as the reference's tensor expression (ddp.py:857-860, 630-634) and the stem kernels
+        const float v = axpby_rn(a.sqrt_ac[t], a.x[i], a.sign * a.sqrt_1mac[t], a.y[i]);
         a.out[i] = a.post_scale[c] * v + a.post_shift[c];
     }
 }

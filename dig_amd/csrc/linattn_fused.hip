@@ -122,8 +122,11 @@ __device__ __forceinline__ void kv_tile(const T* xs, const Frag<T>* fk, const Fr
         }
 }
 
+#ifndef LA_KV_WAVES
+#define LA_KV_WAVES 2
+#endif
 template <typename T, int KS, bool WREG>
-__global__ __launch_bounds__(256, (KS * (int)sizeof(T) <= 16 ? 2 : 1)) void la_kv_ctx_kernel(dig_la_kvctx_args a) {
+__global__ __launch_bounds__(256, (KS * (int)sizeof(T) <= 8 ? LA_KV_WAVES : (KS * (int)sizeof(T) <= 16 ? 2 : 1))) void la_kv_ctx_kernel(dig_la_kvctx_args a) {
     constexpr int C = KS * 16, CP = C + 8, TP = 64;
     constexpr int LPR = C / 8;                       // lanes that share one pixel row while staging
     constexpr int NV = (TP * LPR + 255) / 256;       // 16-byte vectors per thread per tile

@@ -63,8 +63,8 @@ template <typename T> __global__ __launch_bounds__(256) void stem_kernel(dig_ste
             float v = 0.f;
             if (Y >= 0 && Y < a.H && X >= 0 && X < a.W) {
                 const size_t idx = ((size_t)b * 3 + c) * HW + (size_t)Y * a.W + X;
-                const float x0 = a.pre_scale[c] * a.img[idx] + a.pre_shift[c];
-                v = ca * x0 + cs * a.noise[idx];
+                const float x0 = __builtin_fmaf(a.pre_scale[c], a.img[idx], a.pre_shift[c]);
+                v = axpby_rn(ca, x0, cs, a.noise[idx]);  // as stem64_kernel and dig_sched_axpby: x_t is bit-identical everywhere
                 if (a.x_t && hy >= 3 && hy < 3 + TH && hx >= 3 && hx < 3 + TW) a.x_t[idx] = v;
             }
             halo[(c * HH + hy) * (HW_ + 1) + hx] = v;
@@ -188,7 +188,11 @@ __global__ __launch_bounds__(256, 2) void stem64_kernel(dig_stem_args a, int til
             const bool ok = Y >= 0 && Y < a.H && X >= 0 && X < a.W;
             float v[3];
 #pragma unroll
-            for (int c = 0; c < 3; c++) v[c] = ok ? ca * (a.pre_scale[c] * pimg[i][c] + a.pre_shift[c]) + cs * pnz[i][c] : 0.f;
+            // explicitly rounded operations (ddp.py:857-860 is two multiplications and an addition): this lambda is inlined at
+            // two call sites (first tile / steady state) and under -ffp-contract=fast the two copies would otherwise contract
+            // differently, i.e. round a halo pixel differently from the tile that owns it
+            for (int c = 0; c < 3; c++)
+                v[c] = ok ? axpby_rn(ca, __builtin_fmaf(a.pre_scale[c], pimg[i][c], a.pre_shift[c]), cs, pnz[i][c]) : 0.f;
             if (a.x_t && ok && hy >= 3 && hy < 3 + S_TH && hx >= 3 && hx < 3 + S_TW) {
                 const size_t o = (size_t)b * 3 * HW + (size_t)Y * a.W + X;
 #pragma unroll

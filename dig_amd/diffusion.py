@@ -338,6 +338,11 @@ def _linear_attention_unfused(p, x):
     return ops.rmsnorm(y, p["g2"], res=x)
 
 
+def la_splits(n):
+    """Pixel splits of the fused LinearAttention's pass A for an image of n pixels (independent of the batch size)."""
+    return max(1, min(32, ((n + 63) // 64) // 4))
+
+
 def _linear_attention(p, x):
     """LinearAttention (ddp.py:196-233) + the caller's residual (ddp.py:402,430), fused: pass A (k, v, online softmax,
     context) -> merge + M_b -> pass B (q, softmax, M_b q, RMSNorm, residual).  x is read twice, the result written once."""
@@ -349,7 +354,9 @@ def _linear_attention(p, x):
     dt = x.dtype
     dc = dtype_code(dt)
     tiles = (n + 63) // 64
-    splits = max(1, min(64, tiles // 4, max(1, 512 // B)))  # ~512 blocks in pass A; fewer, longer splits merge cheaper
+    # pixel splits of pass A: a function of n ONLY, so that an image goes through the same fp32 merge order whatever batch
+    # it sits in (a rank's shard of a batch is then bitwise equal to the same images inside the full batch)
+    splits = la_splits(n)
     part = torch.empty(B, splits, 4, 32, 32, dtype=torch.float32, device=x.device)
     pmax = torch.empty(B, splits, 4, 32, dtype=torch.float32, device=x.device)
     psum = torch.empty(B, splits, 4, 32, dtype=torch.float32, device=x.device)
@@ -401,13 +408,26 @@ def _same_device(module, dev, what):
                                f"move the module with .to('{dev}') first (no CPU fallback)")
 
 
+def _mark_t_checked(t, num_timesteps):
+    """Remember on the tensor OBJECT (not its storage address, which the allocator reuses) that its current version holds
+    valid timesteps; an in-place write bumps _version and voids the mark."""
+    t._dig_t_ok = (t._version, num_timesteps)
+    return t
+
+
 def _check_t(t, num_timesteps, B):
     """extract() in the reference (ddp.py:452-455) is a gather that raises on an out-of-range index; here the tables are
-    indexed by the kernels directly, so validate on the host."""
+    indexed by the kernels directly, so validate on the host.  Reading a device tensor back costs a stream sync, so a
+    validated tensor object is marked: a loop that reuses its `t` (bench.py, a serving loop) pays once, and
+    dig_amd.guidance marks the tensors it builds from Python ints."""
     if t.dim() != 1 or t.shape[0] != B:
         raise ValueError(f"t must have shape [{B}], got {tuple(t.shape)}")
-    if B and (int(t.min()) < 0 or int(t.max()) >= num_timesteps):
-        raise IndexError(f"timestep out of range: t must lie in [0, {num_timesteps}), got [{int(t.min())}, {int(t.max())}]")
+    if not B or getattr(t, "_dig_t_ok", None) == (t._version, num_timesteps):
+        return
+    lo, hi = (int(v) for v in torch.aminmax(t))
+    if lo < 0 or hi >= num_timesteps:
+        raise IndexError(f"timestep out of range: t must lie in [0, {num_timesteps}), got [{lo}, {hi}]")
+    _mark_t_checked(t, num_timesteps)
 
 
 def _unet_forward(u, img, noise, t, sqrt_ac, sqrt_1mac, pre_scale, pre_shift, want_xt, debug=None):
@@ -557,8 +577,8 @@ class GaussianDiffusion(nn.Module):
         if self.sqrt_alphas_cumprod.device != x.device or y.device != x.device:
             raise RuntimeError(f"dig_amd.GaussianDiffusion: schedule buffers on {self.sqrt_alphas_cumprod.device}, operands on "
                                f"{x.device} / {y.device}; move the module with .to(device) first")
-        t = t.to(x.device)
         _check_t(t, self.num_timesteps, B)
+        t = t.to(x.device)
         out = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
         call("sched_axpby", x=x.contiguous().float(), y=y.contiguous().float(), t=t.to(torch.long).contiguous(),
              sqrt_ac=self.sqrt_alphas_cumprod, sqrt_1mac=self.sqrt_one_minus_alphas_cumprod, out=out,

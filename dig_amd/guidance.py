@@ -7,6 +7,7 @@ predict_start_from_v + unnormalize + normforCls into one elementwise kernel."""
 import torch
 
 from ._lib import call
+from .diffusion import _mark_t_checked
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
@@ -21,6 +22,8 @@ def extract_guidance(diffusion, img, noises=None, t_list=T_LIST, sfi=100, batche
     assert img.is_cuda, "dig_amd.guidance runs on the HIP device only"
     B = img.shape[0]
     dev = img.device
+    if any(not (0 <= int(tv) < diffusion.num_timesteps) for tv in t_list):
+        raise IndexError(f"timestep out of range: t_list {tuple(t_list)} must lie in [0, {diffusion.num_timesteps})")
     if noises is None:
         noises = [torch.randn_like(img) for _ in t_list]
     # x0 = ((img*std + mean)*2 - 1)  ->  pre_scale = 2*std, pre_shift = 2*mean - 1
@@ -31,20 +34,20 @@ def extract_guidance(diffusion, img, noises=None, t_list=T_LIST, sfi=100, batche
     if batched and len(low) > 1:
         xs = img.repeat(len(low), 1, 1, 1)
         nz = torch.cat([noises[j] for j in low], 0)
-        tt = torch.cat([torch.full((B,), t_list[j], dtype=torch.long, device=dev) for j in low])
+        tt = _mark_t_checked(torch.cat([torch.full((B,), t_list[j], dtype=torch.long, device=dev) for j in low]), diffusion.num_timesteps)
         diffusion.p_losses(xs, tt, noise=nz, pre_scale=pre_scale, pre_shift=pre_shift)
         allm = diffusion.model._last_maps
         for i, j in enumerate(low):
             maps[j] = allm[i * B:(i + 1) * B]
     else:
         for j in low:
-            tt = torch.full((B,), t_list[j], dtype=torch.long, device=dev)
+            tt = _mark_t_checked(torch.full((B,), t_list[j], dtype=torch.long, device=dev), diffusion.num_timesteps)
             diffusion.p_losses(img, tt, noise=noises[j], pre_scale=pre_scale, pre_shift=pre_shift)
             maps[j] = diffusion.model._last_maps
     img_diff = None
     for j in range(len(t_list)):
         if t_list[j] == sfi:
-            tt = torch.full((B,), sfi, dtype=torch.long, device=dev)
+            tt = _mark_t_checked(torch.full((B,), sfi, dtype=torch.long, device=dev), diffusion.num_timesteps)
             x_t, v, _ = diffusion.p_losses(img, tt, noise=noises[j], pre_scale=pre_scale, pre_shift=pre_shift)
             # normforCls(unnormalize(predict_start_from_v)) = ((a*x_t - s*v + 1)/2 - mean)/std
             img_diff = diffusion._axpby(x_t, v, tt, -1.0, post_scale=tuple(0.5 / s for s in IMAGENET_STD),

@@ -21,6 +21,12 @@ for ph in range(0, 12):
         row.append(f"w{w}: {a:7d} +{b-a:6d} +{c-b:6d}" + (f" [gl {s3-a:5d} E1 {s4-s3:5d} E2 {s5-s4:5d} ls {b-s5:5d}]" if stage else " " * 41))
     print(f"ph{ph-1:3d} ", " | ".join(row))
 
+comp, stg = [], []
+for ph in range(3, 12):
+    for w in (0, 4):
+        a, b = buf[(w * 64 + ph) * 8 + 0], buf[(w * 64 + ph) * 8 + 1]
+        (stg if (ph - 1 - (w >> 2)) & 1 else comp).append(b - a)
+print("SUMMARY %s compute %.0f stage %.0f" % (os.environ.get("DIG_HIP_LIB", "default").split("lib_")[-1], sum(comp) / len(comp), sum(stg) / len(stg)))
 blk = (ctypes.c_ulonglong * 512)()
 print("rc", L.dig_debug_ws_blk(blk))
 cyc = [blk[2 * i] for i in range(256)]
