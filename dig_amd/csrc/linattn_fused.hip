@@ -452,6 +452,56 @@ extern "C" int dig_la_merge(const dig_la_merge_args* a, void* stream_) {
     return DIG_OK;
 }
 
+// ---- allocation-free variant of the context computation (dig_la_kvctx + dig_la_merge) -----------------------------------
+// The split partials (part / pmax / psum) that dig_la_kvctx takes as a caller-allocated workspace live here in a file-scope
+// device array, so a caller that cannot allocate (HIP graph capture, a serving loop with a frozen memory pool) needs
+// nothing but its inputs and outputs.  In host code the array's NAME is only a stand-in: its device address is taken once
+// per device with hipGetSymbolAddress and only that pointer is ever handed to kernels.
+#define LA_NOALLOC_MAX_SLOTS 1024                                   /* B * splits */
+#define LA_NOALLOC_PART_BYTES ((size_t)LA_NOALLOC_MAX_SLOTS * 4 * 1024 * sizeof(float))
+#define LA_NOALLOC_VEC_BYTES ((size_t)LA_NOALLOC_MAX_SLOTS * 4 * 32 * sizeof(float))
+static __device__ __align__(256) unsigned char la_scratch[LA_NOALLOC_PART_BYTES + 2 * LA_NOALLOC_VEC_BYTES];  // 17.3 MB per GPU
+
+#include <mutex>
+static std::mutex la_scratch_mu;
+static unsigned char* la_scratch_ptr[64] = {};  // per device: each GPU holds its own copy of the array at its own address
+
+extern "C" int dig_la_ctx_noalloc_max_slots(void) { return LA_NOALLOC_MAX_SLOTS; }
+
+extern "C" int dig_la_ctx_noalloc(const dig_la_ctx_noalloc_args* a, void* stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    DIG_CHECK(a && a->x && a->wkv && a->ctx, DIG_EINVAL, "la_ctx_noalloc: null pointer");
+    DIG_CHECK(a->B > 0 && a->n > 0 && a->splits > 0 && a->hid == 128 && a->B <= 65535, DIG_EINVAL, "la_ctx_noalloc: bad shape (needs 4 heads x 32)");
+    DIG_CHECK((long long)a->B * a->splits <= LA_NOALLOC_MAX_SLOTS, DIG_EINVAL,
+              "la_ctx_noalloc: B * splits = %lld exceeds the static scratch (%d slots); use dig_la_kvctx + dig_la_merge with a caller workspace",
+              (long long)a->B * a->splits, LA_NOALLOC_MAX_SLOTS);
+    int dev = 0;
+    DIG_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, DIG_ELAUNCH, "la_ctx_noalloc: cannot query the current device");
+    unsigned char* base;
+    {
+        std::lock_guard<std::mutex> lock(la_scratch_mu);
+        if (!la_scratch_ptr[dev]) {
+            void* ptr = nullptr;
+            hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(la_scratch));
+            DIG_CHECK(e == hipSuccess && ptr, DIG_ELAUNCH, "la_ctx_noalloc: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+            la_scratch_ptr[dev] = (unsigned char*)ptr;
+        }
+        base = la_scratch_ptr[dev];
+    }
+    dig_la_kvctx_args k;
+    k.x = a->x; k.wkv = a->wkv;
+    k.part = (float*)base;
+    k.pmax = (float*)(base + LA_NOALLOC_PART_BYTES);
+    k.psum = (float*)(base + LA_NOALLOC_PART_BYTES + LA_NOALLOC_VEC_BYTES);
+    k.B = a->B; k.n = a->n; k.C = a->C; k.hid = a->hid; k.splits = a->splits; k.dtype = a->dtype;
+    int rc = dig_la_kvctx(&k, stream_);  // every slot < B * splits is fully rewritten: nothing has to start at zero
+    if (rc != DIG_OK) return rc;
+    dig_la_merge_args m;
+    m.part = k.part; m.pmax = k.pmax; m.psum = k.psum; m.ctx = a->ctx; m.B = a->B; m.splits = a->splits; m.dtype = a->dtype;
+    (void)st;
+    return dig_la_merge(&m, stream_);
+}
+
 extern "C" int dig_la_out(const dig_la_out_args* a, void* stream_) {
     hipStream_t st = (hipStream_t)stream_;
     DIG_CHECK(a && a->x && a->wq && a->mb && a->bias && a->g2 && a->out, DIG_EINVAL, "la_out: null pointer");

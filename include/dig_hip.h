@@ -245,6 +245,24 @@ typedef struct {
 } dig_la_out_args;
 int dig_la_out(const dig_la_out_args* a, void* stream);
 
+/* ---- allocation-free LinearAttention context: dig_la_kvctx followed by dig_la_merge, without a caller workspace ----------
+ * NO COUNTERPART IN THE REFERENCE (it has no workspace notion at all).  It exists for callers that cannot allocate device
+ * memory around the call: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  The split
+ * partials that dig_la_kvctx takes as (part, pmax, psum) live in a static device array inside the library instead
+ * (17.3 MB per GPU, held until the process ends); the caller passes only the input, the weights and the output.
+ *   x [B][n][C], wkv [256][C] (as dig_la_kvctx)  ->  ctx [B*4][32 d][32 e] in dtype (as dig_la_merge).
+ * Limit: B * splits <= dig_la_ctx_noalloc_max_slots() (1024), else DIG_EINVAL with a message.  Results are bit-identical
+ * to dig_la_kvctx + dig_la_merge with the same `splits`.  Calls no hipMalloc / hipFree / allocating routine and does not
+ * synchronise.  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race. */
+typedef struct {
+    const void* x;
+    const void* wkv;
+    void* ctx;
+    int B, n, C, hid, splits, dtype;
+} dig_la_ctx_noalloc_args;
+int dig_la_ctx_noalloc_max_slots(void);
+int dig_la_ctx_noalloc(const dig_la_ctx_noalloc_args* a, void* stream);
+
 /* ---- stem: normalisation + q_sample + conv7x7 -------------------------------------------------------
  * Replaces denormforDiff/normalize (model.py:499-508, ddp.py:82-83), extract + q_sample (ddp.py:452-455,
  * 853-860) and init_conv (ddp.py:296,388).  img, noise: NCHW fp32 [B][3][H][W];
