@@ -36,6 +36,12 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--t", type=int, default=100)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch images per rank (default, the headline); strong: --batch is the GLOBAL batch, split over the ranks "
+                         "(BASELINE.json configs[3]: global batch 32 -> 32/N images per GPU)")
+    ap.add_argument("--timesteps", type=int, default=1,
+                    help="k > 1: every image runs at t = 0..k-1 as ONE batched forward of k x batch images (the guidance loop's "
+                         "per-step shape, model.py:296-314 / configs[3]); a map is still one (image, timestep) forward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-collective", action="store_true",
                     help="N = 1 only: initialise RCCL with one rank and run the N > 1 code path (async all-gather, barrier, MAX reduce) - a rehearsal, not a measurement")
@@ -65,7 +71,13 @@ def main():
     torch.set_grad_enabled(False)
 
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    B, S = args.batch, args.size
+    S = args.size
+    if args.scaling == "strong":
+        assert args.batch % world == 0, f"--scaling strong needs the global batch {args.batch} to divide over {world} ranks"
+        B_img = args.batch // world
+    else:
+        B_img = args.batch
+    B = B_img * args.timesteps  # rows of the batched forward on this rank
     unet = Unet(dim=64, dim_mults=(1, 2, 4, 8), flash_attn=True)
     synth.fill_state_dict(unet, seed=0)
     gd = GaussianDiffusion(unet, image_size=S, timesteps=1000, sampling_timesteps=150).eval()
@@ -73,9 +85,13 @@ def main():
     gd = gd.to(dev)
     unet.set_compute_dtype(dt)
     # synthetic inputs, resident in HBM before the timed region; each rank gets its own images
-    x0 = synth.synth_images(B, S, S, seed=1234 + rank * B).to(dev)
+    x0 = synth.synth_images(B_img, S, S, seed=1234 + rank * B_img).to(dev)
+    if args.timesteps > 1:  # the same images at t = 0..k-1, each with its own noise, as one batch (dig_amd.guidance does the same)
+        x0 = x0.repeat(args.timesteps, 1, 1, 1)
+        t = torch.arange(args.timesteps, device=dev).repeat_interleave(B_img)
+    else:
+        t = torch.full((B,), args.t, dtype=torch.long, device=dev)
     nz = synth.synth_noise(B, S, S, seed=1235 + rank * B).to(dev)
-    t = torch.full((B,), args.t, dtype=torch.long, device=dev)
     h = S // 16
     from dig_amd.dist import PipelinedGather
     gather = PipelinedGather((B, 1024, h, h), torch.float32, dev, force=args.rehearse_collective) if multi else None
@@ -158,7 +174,9 @@ def main():
         ach = fl / sec / 1e12
         # HBM bytes per launch of this kernel class from the committed PMC passes (tools/pmc_traffic.py; bf16, B=32, 256x256 only)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        if not os.path.exists(tpath):
+            tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(tpath) and dt == torch.bfloat16 and B == 32 and S == 256:
             with open(tpath) as f:
                 traffic = json.load(f)["classes"].get(dom, {}).get("hbm_bytes_per_launch")
@@ -174,14 +192,24 @@ def main():
     whole = {"tflops": round(maps_per_s / world * gflop / 1e3, 2), "frac_of_mfma_peak": round(maps_per_s / world * gflop / 1e3 / peak, 4)} if gflop else None
 
     # ---- CPU baseline: the oracle (a port of the reference graph) on the host cores, bounded sample
-    cpu = None
+    cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import dig_oracle as O
         cores = min(16, os.cpu_count() or 1)
         torch.set_num_threads(cores)
         cx, cn, ct = x0[:1].cpu(), nz[:1].cpu(), t[:1].cpu()
-        O.p_losses_eval(cpu_sd, cx, ct, cn)  # warm-up
+        ox, ov, of = O.p_losses_eval(cpu_sd, cx, ct, cn)  # warm-up; doubles as the parity check of image 0 of the timed batch
+        gx, gv, gf = gd.p_losses(x0, t, noise=nz)
+        torch.cuda.synchronize()
+        parity = {"what": "max-abs |HIP - CPU oracle (fp32)| on image 0 of the timed batch, per output (max|oracle| beside it)",
+                  "x_t": [float((gx[:1].cpu() - ox).abs().max()), float(ox.abs().max())],
+                  "v": [float((gv[:1].cpu() - ov).abs().max()), float(ov.abs().max())]}
+        for j, (a_, b_) in enumerate(zip(gf, of)):
+            parity[f"map{j}"] = [float((a_[:1].cpu() - b_).abs().max()), float(b_.abs().max())]
+        tol = 1e-3 if dt == torch.float32 else 2e-2
+        parity["tolerance"] = f"{tol:g} * max(1, max|oracle|)" if dt == torch.bfloat16 else "1e-3"
+        parity["ok"] = all(v_[0] <= tol * max(1.0, v_[1]) for k_, v_ in parity.items() if isinstance(v_, list))
         n_done, c0 = 0, time.perf_counter()
         while n_done < 10 and time.perf_counter() - c0 < 15.0:
             O.p_losses_eval(cpu_sd, cx, ct, cn)
@@ -193,13 +221,16 @@ def main():
     if rank == 0:
         out = {"metric": "guidance maps/sec (Unet fwd 256x256, bs32)", "value": round(maps_per_s, 2), "unit": "maps/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+               "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype,
                "data": "synthetic" + (" (REHEARSAL of the N > 1 code path with one RCCL rank)" if args.rehearse_collective else ""),
-               "config": {"workload": f"BASELINE.json configs[1]: batch-{B} Unet(dim=64, mults 1,2,4,8) guidance extraction at {S}x{S}, "
-                                      f"t={args.t}, q_sample + Unet eval forward + 5 guidance maps -> [B,1024,{h},{h}]",
-                          "per_gpu_batch": B, "global_batch": world * B, "image": S, "parallelism": f"dp{world}",
-                          "collective": "all_gather_into_tensor(maps fp32 [B,1024,h,w]), overlapped with the next step" if world > 1 else "none"},
-               "whole_forward": whole, "roofline": roof, "cpu_baseline": cpu}
+               "config": {"workload": (f"BASELINE.json configs[1]: batch-{B} Unet(dim=64, mults 1,2,4,8) guidance extraction at {S}x{S}, "
+                                       f"t={args.t}, q_sample + Unet eval forward + 5 guidance maps -> [B,1024,{h},{h}]") if args.timesteps == 1 else
+                                      (f"BASELINE.json configs[3]: {B_img} images/GPU x t=0..{args.timesteps - 1} as one batch of {B} Unet(dim=64) "
+                                       f"guidance forwards at {S}x{S} -> [{B_img},{args.timesteps},1024,{h},{h}]"),
+                          "per_gpu_batch": B, "global_batch": world * B, "images_per_gpu": B_img, "timesteps_batched": args.timesteps,
+                          "image": S, "parallelism": f"dp{world}",
+                          "collective": "all_gather_into_tensor(maps fp32 [B,1024,h,w] - fp32 because the maps' consumer (LFCA, model.py:322) and the reference's own feat tensors are fp32), overlapped with the next step" if world > 1 else "none"},
+               "whole_forward": whole, "roofline": roof, "cpu_baseline": cpu, "parity": parity}
         print(json.dumps(out))
     if multi:
         dist.destroy_process_group()
