@@ -11,11 +11,14 @@
 // LDS pixel stride is KC+8 elements and the halo row stride is padded to a multiple of 256 B so that the
 // 16-lane groups of ds_read_b128 hit 16 distinct 16-B slots (conflict-free A and B fragment reads).
 #include "common.hpp"
+#include <cstdlib>
 
 // weight-stationary persistent variant for 64 -> 64 bf16 layers (conv3x3_ws.hip)
 bool conv3x3_ws64_eligible(int H, int W, int C0, int C1, int Cout, int groups, int dtype);
 int conv3x3_ws64_launch(const dig_conv3x3_args* a, hipStream_t stream);
 // double-buffered 8-wave variant for the wide bf16 layers (conv3x3_db.hip): 32x16-pixel tiles
+bool conv3x3_rs128_eligible(int H, int W, int C0, int C1, int Cout, int groups, int dtype, bool has_aff);
+int conv3x3_rs128_launch(const dig_conv3x3_args* a, hipStream_t stream);
 bool conv3x3_db_eligible(int C0, int C1, int Cout, int dtype);
 int conv3x3_db_launch(const dig_conv3x3_args* a, hipStream_t stream);
 
@@ -406,6 +409,10 @@ extern "C" int dig_conv3x3(const dig_conv3x3_args* a, void* stream_) {
     if (conv3x3_ws64_eligible(a->H, a->W, a->C0, a->in1 ? a->C1 : 0, a->Cout, a->stats ? a->groups : 8, a->dtype))
         return conv3x3_ws64_launch(a, stream);
     if (conv3x3_db_eligible(a->C0, a->in1 ? a->C1 : 0, a->Cout, a->dtype)) return conv3x3_db_launch(a, stream);
+    // 128 -> 64 without a GroupNorm prologue: register-stationary weights (same GroupNorm partial count as the generic kernel)
+    if (conv3x3_rs128_eligible(a->H, a->W, a->C0, a->in1 ? a->C1 : 0, a->Cout, a->stats ? a->groups : 8, a->dtype, a->aff0 != nullptr) &&
+        !getenv("DIG_NO_RS128"))
+        return conv3x3_rs128_launch(a, stream);
     if (a->dtype == DIG_BF16) {
         if (BN == 128) return launch<bf16, 128, 16, CONV_PF128, 4, CONV_WNG128>(a, stream);
         if (BN == 64) return launch<bf16, 64, CONV_KC64, CONV_PF64, CONV_WPG64, 1>(a, stream);

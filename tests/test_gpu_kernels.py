@@ -316,6 +316,43 @@ def test_conv3x3_weight_stationary_64(shape, monkeypatch):
         assert (nchw(y) - ref).abs().max() <= tol(dt, ref)
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 48, 64, 0), (1, 16, 16, 64, 0), (3, 64, 32, 0, 0), (1, 112, 112, 64, 0), (3, 64, 32, 64, 3), (2, 48, 80, 0, 1),
+                                   (5, 32, 32, 64, 2), (1, 16, 32, 0, 1)])
+def test_conv3x3_register_stationary_128_to_64(shape, monkeypatch):
+    """The persistent register-stationary 128->64 bf16 kernel (conv3x3_rs.hip): (x | skip) concat of two 64-channel tensors
+    (C1 = 64) or one 128-channel tensor (C1 = 0), GroupNorm partials (one per tile and group), nearest-x2 addressing, border and
+    interior tiles, against F.conv2d in fp32 - and against the generic kernel (DIG_NO_RS128) within one bf16 rounding.  The last
+    cases force a tiny grid (DIG_RS_GRID) so that every block walks many tiles across image boundaries (K = 1 and odd K too)."""
+    dt = torch.bfloat16
+    B, H, W, C1, grid = shape
+    C0 = 128 - C1
+    if grid:
+        monkeypatch.setenv("DIG_RS_GRID", str(grid))
+    x0 = q(rnd("rsx0", (B, C0, H, W)), dt)
+    x1 = q(rnd("rsx1", (B, C1, H, W)), dt) if C1 else None
+    w, b = q(rnd("rsw", (64, 128, 3, 3), (3.0 / (9 * 128)) ** 0.5), dt), rnd("rsb", (64,), 0.1)
+    cw = ops.ConvWeight(w.to(DEV), b.to(DEV), dt, C1=C1)
+    ref = F.conv2d(torch.cat([x0, x1], 1) if C1 else x0, w, b, padding=1)
+    y, st = ops.conv3x3(nhwc(x0, dt), cw, x1=nhwc(x1, dt) if C1 else None)
+    assert st.shape[2] == (H // 16) * (W // 16)
+    assert (nchw(y) - ref).abs().max() <= tol(dt, ref)
+    g = ref.reshape(B, 8, -1).double()
+    ssum = st.cpu().double().sum(2)
+    assert torch.allclose(ssum[..., 0], g.sum(-1), rtol=1e-3, atol=1e-2 * g.shape[-1] ** 0.5)
+    assert torch.allclose(ssum[..., 1], (g * g).sum(-1), rtol=2e-3)
+    y2, st2 = ops.conv3x3(nhwc(x0, dt), cw, x1=nhwc(x1, dt) if C1 else None)
+    assert torch.equal(y, y2) and torch.equal(st, st2)  # deterministic
+    monkeypatch.setenv("DIG_NO_RS128", "1")
+    yg, stg = ops.conv3x3(nhwc(x0, dt), cw, x1=nhwc(x1, dt) if C1 else None)
+    monkeypatch.delenv("DIG_NO_RS128")
+    assert (y.float() - yg.float()).abs().max().item() <= 2.0 ** -7 * max(1.0, float(ref.abs().max()))
+    assert torch.allclose(st.double().sum(2), stg.double().sum(2), rtol=1e-4, atol=1e-2)
+    if C1 == 0 and H <= 64:
+        ref = F.conv2d(F.interpolate(x0, scale_factor=2, mode="nearest"), w, b, padding=1)
+        y, _ = ops.conv3x3(nhwc(x0, dt), cw, up2=True, want_stats=False)
+        assert tuple(y.shape) == (B, 2 * H, 2 * W, 64) and (nchw(y) - ref).abs().max() <= tol(dt, ref)
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 32, 64, 64, 64), (3, 16, 32, 128, 64, 128), (1, 64, 96, 64, 64, 64)])
 def test_pw_res_tail(shape):
     """dig_pw_res (streaming ResnetBlock tail) vs conv1x1([x0|x1]) + SiLU(a*h2+b) in fp32, and vs the general GEMM path."""
