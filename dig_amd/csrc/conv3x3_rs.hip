@@ -12,16 +12,23 @@
 //     the compiler spreads them over the VGPR and accumulator halves, MFMA reads A/B operands from either).
 //   * LDS holds nothing but activations: a ring of three 18x18-pixel x 64-channel halo chunks (one per K half: the
 //     x part and the skip part of the concat, or the two channel halves of a 128-channel source), filled by LDS-DMA
-//     (global_load_lds_dwordx4: no registers, no VALU, no LDS store instructions) two chunks ahead of the MFMAs.  Rows are
+//     (global_load_lds_dwordx4: no registers, no VALU, no LDS store instructions) one chunk ahead of the MFMAs.  Rows are
 //     128 B with the 16-byte slots XOR-swizzled by (hx >> 1) & 7 - applied to the per-lane SOURCE address, the LDS side of
 //     a DMA being linear - so every ds_read_b128 fragment read is conflict-free.  Fused here: channel concat, nearest-x2
 //     upsampling (source addressing), zero padding (border tiles: out-of-image pixels are zeroed in LDS after the DMA landed).
 //   * one s_barrier per chunk; DMA completion is tracked with counted s_waitcnt vmcnt(N) (the DMAs and the output stores are
 //     the only vector-memory operations of the steady state, their numbers per chunk are fixed).
-//   * per tile: accumulators (+bias) -> bf16 -> the wave's own 8 KB LDS slice -> 16-byte stores of 64-byte half rows (both
-//     halves of a 128-byte line are written by the two nh waves within the same tile, they merge in L2); GroupNorm partial
-//     sums from the fp32 accumulators, one (sum, sumsq) pair per (tile, group) - the two pixel halves are combined through
-//     LDS one barrier later, so the partial count equals the generic kernel's (dig_conv3x3_tiles is unchanged).
+//   * per tile: accumulators (initialised with the bias) -> bf16 -> the wave's own 8 KB LDS slice (the only part of the
+//     epilogue the MFMA pipe waits for); the slice -> 16-byte stores of 64-byte half rows (both halves of a 128-byte line are
+//     written by the two nh waves within the same tile, they merge in L2) and the GroupNorm partial sums of the STORED bf16
+//     values run between the MFMAs of the next tile's first chunk.  One (sum, sumsq) pair per (tile, group): the two pixel
+//     halves are combined through LDS one barrier later, so the partial count equals the generic kernel's.
+// Measured (B = 32, 256x256, MI355X): 329 us against the generic kernel's 354 us.  What bounds it (per-chunk s_memtime trace,
+// -DRS_TRACE): with ONE wave per SIMD every vector-memory instruction that finds the CU's memory pipeline full blocks the
+// wave that also issues the MFMAs; a tile moves 115 KB (DMA pieces + stores) at the CU's share of HBM (~14 B/clk), i.e.
+// ~8.0 k cycles of issue blocking on top of 9.2 k cycles of MFMAs, whatever the prefetch distance or placement (DIST 1 / 2,
+// early / late / spread issue all land within 2 %).  Hiding it needs a second wave per SIMD, which 288 weight registers
+// exclude: the design trades the generic kernel's weight re-staging (262 KB of L2 traffic per tile) for that serialisation.
 // A/B fragment reads use the inline-asm ring of conv3x3_ws.hip (tools/check_async_lds_asm.py checks this kernel as well).
 #include "common.hpp"
 #include <cstdio>
@@ -40,6 +47,24 @@ constexpr int SLICE = 8192;            // per-wave epilogue slice: [128 px][32 c
 constexpr int ST_OFF = EPI_OFF + 4 * SLICE;
 constexpr int RS_LDS = ST_OFF + 16 * 4 + 64 * 4;  // + stats exchange [2 nh][8] + bias [64]
 constexpr int NSTORE = 8;              // output store instructions per wave per tile
+#ifndef RS_DIST
+#define RS_DIST 1                      // chunks between a DMA's issue and its use
+#endif
+#ifndef RS_S0
+#define RS_S0 0                        // compute step of the first DMA piece of a chunk
+#endif
+#ifndef RS_SS
+#define RS_SS 1                        // steps between pieces
+#endif
+constexpr int DIST = RS_DIST, DMA_S0 = RS_S0, DMA_SS = RS_SS, DMA_LAST = DMA_S0 + (NDMA - 1) * DMA_SS;
+static_assert(DMA_LAST < 36, "all pieces of a chunk are issued within one compute phase");
+// output stores are issued at steps 3 + 4 i of a K-half-0 chunk: how many of them come after the chunk's last DMA piece
+constexpr int stores_after_dma() {
+    int n = 0;
+    for (int i = 0; i < NSTORE; i++) n += (3 + 4 * i >= DMA_LAST) ? 1 : 0;
+    return n;
+}
+constexpr int STORES_AFTER = stores_after_dma();
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
@@ -108,6 +133,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* st_l = reinterpret_cast<float*>(smem + ST_OFF);
     float* bias_l = st_l + 16;
     if (tid < 64) bias_l[tid] = p.bias[tid];
+#ifdef RS_TRACE
+    const unsigned long long rs_t0 = __builtin_amdgcn_s_memtime(), rs_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- this wave's 32 x 1152 weight slice: A fragments (rows = channels nh*32 + r, k = 8 hf .. 8 hf + 7 of 16-chunk kk)
     Frag<bf16> wr[2][9][4];
@@ -119,14 +147,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int ks = 0; ks < 4; ks++)
                 frag_load<bf16>(wr[kh][tap][ks], p.w + ((size_t)((kh * 4 + ks) * 9 + tap) * 64 + nh * 32 + r) * 16 + hf * 8);
 
+    // A tile's coordinates, decoded ONCE (two integer divisions) when its prefetch is set up and carried as scalars:
     // linear tile index -> (image, tile inside the image), rotated per image so that every block sees the same mix of
     // border and interior tiles (see conv3x3_ws.hip)
-    auto decode = [&](int t, int& b, int& ty0, int& tx0, int& tl) {
-        b = t / tiles_img;
-        tl = t - b * tiles_img;
-        tl = (int)(((unsigned)tl + (unsigned)b * 37u) % (unsigned)tiles_img);
-        ty0 = (tl / p.tiles_x) * 16;
-        tx0 = (tl % p.tiles_x) * 16;
+    struct Tile {
+        int b, tl, ty0, tx0;
+        bool interior;
+    };
+    auto decode = [&](int t) {
+        Tile q;
+        q.b = t / tiles_img;
+        q.tl = t - q.b * tiles_img;
+        q.tl = (int)(((unsigned)q.tl + (unsigned)q.b * 37u) % (unsigned)tiles_img);
+        const int ty = q.tl / p.tiles_x;
+        q.ty0 = ty * 16;
+        q.tx0 = (q.tl - ty * p.tiles_x) * 16;
+        q.interior = q.ty0 > 0 && q.tx0 > 0 && q.ty0 + 16 < p.H && q.tx0 + 16 < p.W;
+        return q;
     };
     auto tile_of = [&](int k) { return bid + k * G; };
 
@@ -141,18 +178,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto piece_j = [&](int i) { return (wave + 4 * i < NJ) ? wave + 4 * i : wave + 36; };
     unsigned off[NDMA];
     bool off_interior = false;
-    struct Dma {
-        const bf16* base[2];  // scalar: K half 0 / 1 of the tile being prefetched
-    };
-    auto dma_setup = [&](int t, Dma& d) {
+    auto dma_setup = [&](const Tile& q, const bf16* (&base)[2]) {
         int lq = lane >> 3, sv = lane & 7;
         asm volatile("" : "+v"(lq), "+v"(sv));  // recompute per call instead of carrying hoisted address math in registers
-        int b, ty0, tx0, tl;
-        decode(t, b, ty0, tx0, tl);
-        const bool interior = ty0 > 0 && tx0 > 0 && ty0 + 16 < p.H && tx0 + 16 < p.W;  // scalar
         size_t origin = 0;
-        if (interior) {
-            const int sy0 = p.up2 ? (ty0 - 1) >> 1 : ty0 - 1, sx0 = p.up2 ? (tx0 - 1) >> 1 : tx0 - 1;
+        if (q.interior) {
+            const int sy0 = p.up2 ? (q.ty0 - 1) >> 1 : q.ty0 - 1, sx0 = p.up2 ? (q.tx0 - 1) >> 1 : q.tx0 - 1;
             origin = ((size_t)sy0 * Ws + sx0) * p.cpix;
             if (!off_interior) {
 #pragma unroll
@@ -168,25 +199,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int i = 0; i < NDMA; i++) {
                 const int hp = min(piece_j(i) * 8 + lq, HPIX - 1);
                 const int hy = hp / 18, hx = hp - hy * 18;
-                const int Yc = min(max(ty0 + hy - 1, 0), p.H - 1), Xc = min(max(tx0 + hx - 1, 0), p.W - 1);
+                const int Yc = min(max(q.ty0 + hy - 1, 0), p.H - 1), Xc = min(max(q.tx0 + hx - 1, 0), p.W - 1);
                 const int sy = p.up2 ? Yc >> 1 : Yc, sx = p.up2 ? Xc >> 1 : Xc;
                 off[i] = (unsigned)(((sy * Ws + sx) * p.cpix + ((sv ^ ((hx >> 1) & 7)) << 3)) * 2);
             }
         }
-        off_interior = interior;
+        off_interior = q.interior;
 #pragma unroll
-        for (int kh = 0; kh < 2; kh++) d.base[kh] = p.src[kh] + (size_t)b * p.bstride[kh] + origin;
+        for (int kh = 0; kh < 2; kh++) base[kh] = p.src[kh] + (size_t)q.b * p.bstride[kh] + origin;
     };
     auto issue_dma = [&](const bf16* base, int c, int i) {  // piece i of chunk c into ring buffer c % 3
 #ifndef RS_NO_DMA
         dma16(base, off[i], smem_l + (unsigned)((c % NBUF) * CHUNK + piece_j(i) * 1024));
 #endif
     };
-    auto zero_fill = [&](int c) {  // after this wave's pieces of chunk c have landed, before the barrier that publishes them
-        int b, ty0, tx0, tl;
-        decode(tile_of(c >> 1), b, ty0, tx0, tl);
-        const bool interior = ty0 > 0 && tx0 > 0 && ty0 + 16 < p.H && tx0 + 16 < p.W;
-        if (!interior) {
+    auto zero_fill = [&](const Tile& q, int c) {  // after this wave's pieces of chunk c have landed, before the barrier that publishes them
+        if (!q.interior) {
             int lq = lane >> 3, ln = lane;
             asm volatile("" : "+v"(lq), "+v"(ln));
             unsigned char* buf = smem + (c % NBUF) * CHUNK;
@@ -194,22 +222,84 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int i = 0; i < NDMA; i++) {
                 const int j = piece_j(i), hp = j * 8 + lq;
                 const int hy = hp / 18, hx = hp - hy * 18;
-                const int Y = ty0 + hy - 1, X = tx0 + hx - 1;
+                const int Y = q.ty0 + hy - 1, X = q.tx0 + hx - 1;
                 if (hp < HPIX && !(Y >= 0 && Y < p.H && X >= 0 && X < p.W)) *reinterpret_cast<i32x4*>(buf + j * 1024 + ln * 16) = i32x4{0, 0, 0, 0};
             }
         }
     };
 
+    // ---- second half of the epilogue of the PREVIOUS tile, run between the MFMAs of the next chunk (or alone after the last
+    // tile): store row i of the wave's slice (tile row 8 ph + i: 16 pixels x 64 B; lane l: pixel l >> 2, 16-byte slot l & 3)
+    // and accumulate the GroupNorm sums of the slot's 8 channels (group nh * 4 + (l & 3)) from the stored bf16 values.
+    struct Epi {
+        bf16* outw;      // scalar: out + ((b * H + ty0 + 8 ph) * W + tx0) * 64 + nh * 32
+        unsigned rowb;   // scalar: W * 128 (bytes between tile rows)
+        float s, q;      // per-lane running sum / sum of squares
+        bool stats;
+    };
+    auto epi_read = [&](int i, i32x4& od) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int pl = i * 16 + (ln >> 2);
+        od = *reinterpret_cast<const i32x4*>(smem + EPI_OFF + wave * SLICE + pl * 64 + (((ln & 3) ^ ((pl >> 1) & 3)) << 4));
+    };
+    auto epi_store = [&](Epi& e, int i, const i32x4& od) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        *reinterpret_cast<i32x4*>(reinterpret_cast<unsigned char*>(e.outw) + (size_t)i * e.rowb + (unsigned)((ln >> 2) * 128 + (ln & 3) * 16)) = od;
+        if (e.stats) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float x0 = __builtin_bit_cast(float, od[j] << 16), x1 = __builtin_bit_cast(float, od[j] & (int)0xffff0000);
+                e.s += x0;
+                e.q = fmaf(x0, x0, e.q);
+                e.s += x1;
+                e.q = fmaf(x1, x1, e.q);
+            }
+        }
+    };
+    // wave totals of (s, q) per slot: lanes with equal (lane & 3) are reduced; afterwards lanes 0..3 hold group nh * 4 + lane.
+    // The lower pixel half parks them in LDS, the upper one adds them one barrier later (stats_combine).
+    float st_keep_s = 0.f, st_keep_q = 0.f;
+    auto epi_finish = [&](Epi& e) {
+        if (e.stats) {
+            float s = e.s, q = e.q;
+#pragma unroll
+            for (int o = 4; o < 64; o <<= 1) {
+                s += __shfl_xor(s, o, 64);
+                q += __shfl_xor(q, o, 64);
+            }
+            if (ph == 1) {
+                if (lane < 4) {
+                    st_l[nh * 8 + lane] = s;
+                    st_l[nh * 8 + 4 + lane] = q;
+                }
+            } else {
+                st_keep_s = s;
+                st_keep_q = q;
+            }
+        }
+    };
+    auto stats_combine = [&](const Tile& q) {  // after the barrier that follows epi_finish of tile q
+        if (p.stats && ph == 0 && lane < 4) {
+            float* dst = p.stats + (((size_t)q.b * 8 + nh * 4 + lane) * tiles_img + q.tl) * 2;
+            dst[0] = st_keep_s + st_l[nh * 8 + lane];
+            dst[1] = st_keep_q + st_l[nh * 8 + 4 + lane];
+        }
+    };
+
     // ---- compute: 36 (tap, ks) steps of 4 MFMAs on ring buffer c % 3 with the weights of K half KH; the pieces of chunk c + 2
-    // are issued between the steps.  B fragments: pixel tile m = tile rows 8 ph + 2 m, + 1 (32 pixels), k slot 2 ks + hf.
+    // are issued between the steps, and so is the second half of the previous tile's epilogue (KH = 0 only).
+    // B fragments: pixel tile m = tile rows 8 ph + 2 m, + 1 (32 pixels), k slot 2 ks + hf.
     f32x16 acc[4];
-    auto compute = [&](auto khc, int c, const bf16* pf_base) {  // pf_base: source of chunk c + 2, or nullptr
+    auto compute = [&](auto khc, int c, const bf16* pf_base, bool do_epi, Epi& epi) {  // pf_base: source of chunk c + 2, or nullptr
         constexpr int KH = decltype(khc)::value;
 #ifndef RS_PF
 #define RS_PF 1
 #endif
         constexpr int PF = RS_PF, NST = 36;
         i32x4 fb[PF + 1][4];
+        i32x4 od = i32x4{0, 0, 0, 0};
         const unsigned hbase = smem_l + (unsigned)((c % NBUF) * CHUNK);
         int rr = r;
         asm volatile("" : "+v"(rr));
@@ -234,8 +324,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         static_for<0, NST>([&](auto stc) {
             constexpr int st = decltype(stc)::value, slot = st % (PF + 1), tap = st >> 2, ks = st & 3;
             if constexpr (st + PF < NST) fetch(std::integral_constant<int, (st + PF < NST ? st + PF : 0)>{});
-            if constexpr (st % 3 == 0 && st / 3 < NDMA) {
-                if (pf_base) issue_dma(pf_base, c + 2, st / 3);  // scalar branch
+            if constexpr (st >= DMA_S0 && (st - DMA_S0) % DMA_SS == 0 && (st - DMA_S0) / DMA_SS < NDMA) {
+                if (pf_base) issue_dma(pf_base, c + DIST, (st - DMA_S0) / DMA_SS);  // scalar branch
+            }
+            if constexpr (KH == 0) {
+                // previous tile's row i: read at step 1 + 4 i, stored (and summed) two steps later.  These are ordinary LDS /
+                // global operations in program order after the ring's reads: they can only make a counted wait stricter.
+                if constexpr (st % 4 == 1 && st / 4 < NSTORE) {
+                    if (do_epi) epi_read(st / 4, od);
+                }
+                if constexpr (st % 4 == 3 && st / 4 < NSTORE) {
+                    if (do_epi) epi_store(epi, st / 4, od);
+                }
             }
             constexpr int ahead = (NST - 1 - st) < PF ? (NST - 1 - st) : PF;
             lgkm_wait<4 * ahead>(fb[slot][0], fb[slot][1], fb[slot][2], fb[slot][3]);
@@ -245,160 +345,152 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         });
     };
 
-    // ---- epilogue of a finished tile (wave-local: its own LDS slice, its own 64-byte half rows of the output)
-    float st_keep = 0.f;
-    auto epilogue = [&](int t) {
-        int b, ty0, tx0, tl;
-        decode(t, b, ty0, tx0, tl);
+    // ---- first half of the epilogue (the only part the MFMA pipe waits for): accumulators (bias included) -> bf16 -> the
+    // wave's own LDS slice [128 px][32 ch] (rows 64 B, 16-byte slots XOR-swizzled by (px >> 1) & 3), accumulators back to bias
+    auto acc_init = [&]() {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_l + nh * 32 + 8 * q4 + 4 * (ln >> 5));
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[m][4 * q4 + j] = bv[j];
+        }
+    };
+    auto epi_regs = [&]() {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last MFMA retired before the accumulators are read
         __builtin_amdgcn_sched_barrier(0);
-        unsigned char* os = smem + EPI_OFF + wave * SLICE;
         int ln = lane;
-        asm volatile("" : "+v"(ln));  // per-lane epilogue addresses are recomputed per tile (not hoisted and kept live)
-        const int r = ln & 31, hf = ln >> 5, lane = ln;
-        float st[8];  // [kind][q4]
+        asm volatile("" : "+v"(ln));
+        unsigned char* os = smem + EPI_OFF + wave * SLICE;
+        const int r = ln & 31, hf = ln >> 5;
 #pragma unroll
-        for (int j = 0; j < 8; j++) st[j] = 0.f;
-#pragma unroll
-        for (int q4 = 0; q4 < 4; q4++) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_l + nh * 32 + 8 * q4 + 4 * hf);
+        for (int q4 = 0; q4 < 4; q4++)
 #pragma unroll
             for (int m = 0; m < 4; m++) {
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    v[j] = acc[m][4 * q4 + j] + bv[j];
-                    st[q4] += v[j];
-                    st[4 + q4] += v[j] * v[j];
-                }
                 const int pl = m * 32 + r;
-                *reinterpret_cast<bf16x4*>(os + pl * 64 + ((q4 ^ ((pl >> 1) & 3)) << 4) + hf * 8) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                *reinterpret_cast<bf16x4*>(os + pl * 64 + ((q4 ^ ((pl >> 1) & 3)) << 4) + hf * 8) =
+                    bf16x4{(bf16)acc[m][4 * q4], (bf16)acc[m][4 * q4 + 1], (bf16)acc[m][4 * q4 + 2], (bf16)acc[m][4 * q4 + 3]};
             }
-        }
-#pragma unroll
-        for (int m = 0; m < 4; m++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[m][e] = 0.f;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // store i = tile row 8 ph + i: 16 pixels x 64 B (lane l: pixel l >> 2, 16-byte slot l & 3)
-        bf16* outw = p.out + (((size_t)b * p.H + ty0 + ph * 8) * p.W + tx0) * 64 + nh * 32;  // scalar
-        const unsigned lo = (unsigned)((lane >> 2) * 64 + (lane & 3) * 8);
-        bf16x8 od[NSTORE];
-#pragma unroll
-        for (int i = 0; i < NSTORE; i++) {
-            const int pl = i * 16 + (lane >> 2);
-            od[i] = *reinterpret_cast<const bf16x8*>(os + pl * 64 + (((lane & 3) ^ ((pl >> 1) & 3)) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < NSTORE; i++) *reinterpret_cast<bf16x8*>(outw + (size_t)i * p.W * 64 + lo) = od[i];
-        if (p.stats) {
-            // 8 per-lane partials -> wave totals: halving butterfly on lane bits 5, 4, 3 (lane then holds value
-            // j = 4 b5 + 2 b4 + b3 of its 8-lane class), three plain steps finish it; lanes with (lane & 7) == 0 hold j = lane >> 3
-            float a4[4], a2[2], a1;
-            {
-                const bool up = (lane >> 5) & 1;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const float keep = up ? st[4 + j] : st[j], send = up ? st[j] : st[4 + j];
-                    a4[j] = keep + __shfl_xor(send, 32, 64);
-                }
-            }
-            {
-                const bool up = (lane >> 4) & 1;
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    const float keep = up ? a4[2 + j] : a4[j], send = up ? a4[j] : a4[2 + j];
-                    a2[j] = keep + __shfl_xor(send, 16, 64);
-                }
-            }
-            {
-                const bool up = (lane >> 3) & 1;
-                const float keep = up ? a2[1] : a2[0], send = up ? a2[0] : a2[1];
-                a1 = keep + __shfl_xor(send, 8, 64);
-            }
-            a1 += __shfl_xor(a1, 4, 64);
-            a1 += __shfl_xor(a1, 2, 64);
-            a1 += __shfl_xor(a1, 1, 64);
-            // the lower pixel half parks its totals in LDS; the upper one adds them one barrier later (stats_combine)
-            if (ph == 1) {
-                if ((lane & 7) == 0) st_l[nh * 8 + (lane >> 3)] = a1;
-            } else {
-                st_keep = a1;
-            }
-        }
+        acc_init();
     };
-    auto stats_combine = [&](int t) {  // after the barrier that follows epilogue(t)
-        if (p.stats && ph == 0 && (lane & 7) == 0) {
-            int b, ty0, tx0, tl;
-            decode(t, b, ty0, tx0, tl);
-            const int j = lane >> 3, kind = j >> 2, g = nh * 4 + (j & 3);
-            p.stats[(((size_t)b * 8 + g) * tiles_img + tl) * 2 + kind] = st_keep + st_l[nh * 8 + j];
-        }
+    auto epi_setup = [&](const Tile& q, Epi& e) {
+        e.outw = p.out + (((size_t)q.b * p.H + q.ty0 + ph * 8) * p.W + q.tx0) * 64 + nh * 32;
+        e.rowb = (unsigned)p.W * 128u;
+        e.s = e.q = 0.f;
+        e.stats = p.stats != nullptr;
     };
 
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int e = 0; e < 16; e++) acc[m][e] = 0.f;
-    // prologue: weights in registers, then chunks 0 and 1 (tile 0) in flight
-    vm_wait<0>();
-#ifdef RS_TRACE
-    const unsigned long long rs_t0 = __builtin_amdgcn_s_memtime(), rs_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    Dma d;
+    // ---- main loop.  Vector-memory operations of the steady state, per wave: the NDMA pieces of a chunk (issued two chunks
+    // ahead, during compute) and the NSTORE output stores of a tile (issued during the NEXT tile's first chunk); the counted
+    // vmcnt waits below rely on exactly these numbers.  Allowing FEWER outstanding operations than were issued is always
+    // safe, so the single statistics store of the ph = 0 waves and the last store of a chunk are left out of the counts.
+    vm_wait<0>();  // weights in registers
+    __syncthreads();  // bias in LDS
+    acc_init();
+    Tile cur = {}, nxt = {}, prv = {};
+    const bf16* base[2] = {nullptr, nullptr};      // sources of the tile whose pieces are issued next
+    Epi epi = {};
     if (K > 0) {
-        dma_setup(tile_of(0), d);
+        cur = decode(tile_of(0));
+        dma_setup(cur, base);
 #pragma unroll
-        for (int i = 0; i < NDMA; i++) issue_dma(d.base[0], 0, i);
+        for (int i = 0; i < NDMA; i++) issue_dma(base[0], 0, i);
+        if (DIST == 2) {
 #pragma unroll
-        for (int i = 0; i < NDMA; i++) issue_dma(d.base[1], 1, i);
+            for (int i = 0; i < NDMA; i++) issue_dma(base[1], 1, i);
+        }
     }
     for (int k = 0; k < K; k++) {
         const bool more = k + 1 < K;
-        // ---- chunk 2k (K half 0).  Vector-memory operations issued after its pieces: the pieces of chunk 2k + 1 (NDMA)
-        // and, from the second tile on, the NSTORE output stores of tile k - 1 (the statistics store of the ph = 0 waves is
-        // one more: allowing FEWER outstanding operations than were issued is always safe).
+        // ---- chunk 2k (K half 0).  Issued after its pieces - DIST 2: the pieces of chunk 2k + 1 and the late stores of
+        // tile k - 2's... (none: K-half-1 chunks issue no stores) ; DIST 1: nothing (chunk 2k - 1 issues no stores)
         RS_STAMP(2 * k, 0)
-        if (k == 0) vm_wait<NDMA>();
-        else vm_wait<NDMA + NSTORE>();
-        zero_fill(2 * k);
+        if (DIST == 2) vm_wait<NDMA>();
+        else vm_wait<0>();
+        zero_fill(cur, 2 * k);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         RS_STAMP(2 * k, 1)
-        if (k > 0) stats_combine(tile_of(k - 1));
-        if (more) dma_setup(tile_of(k + 1), d);  // offsets + bases of chunks 2k + 2, 2k + 3 (overwrites off[]: tile k's pieces are all issued)
-        compute(std::integral_constant<int, 0>{}, 2 * k, more ? d.base[0] : nullptr);
-        RS_STAMP(2 * k, 2)
-        RS_STAMP(2 * k + 1, 0)
-        // ---- chunk 2k + 1 (K half 1): after its pieces came the stores of tile k - 1 (k > 0) and the pieces of chunk 2k + 2 (more)
-        if (more) {
-            if (k == 0) vm_wait<NDMA>();
-            else vm_wait<NDMA + NSTORE>();
+        const bf16* pf0;  // what compute(2k) prefetches: chunk 2k + DIST
+        if (DIST == 2) {
+            if (more) {
+                nxt = decode(tile_of(k + 1));
+                dma_setup(nxt, base);  // offsets + bases of chunks 2k + 2, 2k + 3 (overwrites off[]: tile k's pieces are all issued)
+            }
+            pf0 = more ? base[0] : nullptr;
         } else {
-            vm_wait<0>();
+            pf0 = base[1];  // chunk 2k + 1 of the same tile
         }
-        zero_fill(2 * k + 1);
+        if (k > 0) epi_setup(prv, epi);
+        compute(std::integral_constant<int, 0>{}, 2 * k, pf0, k > 0, epi);
+        if (k > 0) epi_finish(epi);
+        RS_STAMP(2 * k, 2)
+        // ---- chunk 2k + 1 (K half 1).  Issued after its pieces - DIST 2: in chunk 2k the pieces of chunk 2k + 2 (more) and
+        // the NSTORE stores of tile k - 1 (k > 0); DIST 1: the stores of tile k - 1 that follow the last piece
+        RS_STAMP(2 * k + 1, 0)
+        if (DIST == 2) {
+            if (more) {
+                if (k == 0) vm_wait<NDMA>();
+                else vm_wait<NDMA + NSTORE>();
+            } else {
+                vm_wait<0>();
+            }
+        } else {
+            if (k == 0) vm_wait<0>();
+            else vm_wait<STORES_AFTER>();
+        }
+        zero_fill(cur, 2 * k + 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         RS_STAMP(2 * k + 1, 1)
-        compute(std::integral_constant<int, 1>{}, 2 * k + 1, more ? d.base[1] : nullptr);
+        if (k > 0) stats_combine(prv);
+        const bf16* pf1;
+        if (DIST == 2) {
+            pf1 = more ? base[1] : nullptr;
+        } else {
+            if (more) {
+                nxt = decode(tile_of(k + 1));
+                dma_setup(nxt, base);  // tile k + 1: chunk 2k + 2 now, chunk 2k + 3 during compute(2k + 2)
+            }
+            pf1 = more ? base[0] : nullptr;
+        }
+        compute(std::integral_constant<int, 1>{}, 2 * k + 1, pf1, false, epi);
         RS_STAMP(2 * k + 1, 2)
 #ifndef RS_NO_EPI
-        epilogue(tile_of(k));
+        epi_regs();
 #else
         asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
 #endif
         RS_STAMP(2 * k + 1, 3)
+        prv = cur;
+        cur = nxt;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (K > 0) stats_combine(tile_of(K - 1));
+    // the last tile's stores and sums have no next chunk to hide under
+    if (K > 0) {
+#ifndef RS_NO_EPI
+        epi_setup(prv, epi);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < NSTORE; i++) {
+            i32x4 od;
+            epi_read(i, od);
+            epi_store(epi, i, od);
+        }
+        epi_finish(epi);
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stats_combine(prv);
+    }
 #ifdef RS_TRACE
     if (tid == 0) {
         rs_blk[bid * 2] = __builtin_amdgcn_s_memtime() - rs_t0;

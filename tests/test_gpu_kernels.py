@@ -346,7 +346,8 @@ def test_conv3x3_register_stationary_128_to_64(shape, monkeypatch):
     yg, stg = ops.conv3x3(nhwc(x0, dt), cw, x1=nhwc(x1, dt) if C1 else None)
     monkeypatch.delenv("DIG_NO_RS128")
     assert (y.float() - yg.float()).abs().max().item() <= 2.0 ** -7 * max(1.0, float(ref.abs().max()))
-    assert torch.allclose(st.double().sum(2), stg.double().sum(2), rtol=1e-4, atol=1e-2)
+    # (the generic kernel sums the fp32 accumulators, this one the stored bf16 values: rounding noise of ~1e4 values)
+    assert torch.allclose(st.double().sum(2), stg.double().sum(2), rtol=1e-3, atol=0.5)
     if C1 == 0 and H <= 64:
         ref = F.conv2d(F.interpolate(x0, scale_factor=2, mode="nearest"), w, b, padding=1)
         y, _ = ops.conv3x3(nhwc(x0, dt), cw, up2=True, want_stats=False)
