@@ -152,8 +152,10 @@ __global__ __launch_bounds__(256, (KS * (int)sizeof(T) <= 8 ? LA_KV_WAVES : (KS 
     for (int e = 0; e < 16; e++) ctx[e] = 0.f;
     float m_run = -INFINITY, ksum = 0.f;
     const float sqrtC = sqrtf((float)C);
-    Frag<T> pre[NV];
-    auto gload = [&](int t) {
+    // prefetch depth in tiles (register sets are named: static indexing); the wide instantiations have no registers to spare
+    constexpr int PD = (KS * (int)sizeof(T) <= 8) ? 3 : 1;
+    Frag<T> pre0[NV], pre1[NV], pre2[NV];
+    auto gload = [&](Frag<T>(&pre)[NV], int t) {
 #pragma unroll
         for (int i = 0; i < NV; i++) {
             const int idx = tid + i * 256, row = idx / LPR, v = idx - row * LPR;
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256, (KS * (int)sizeof(T) <= 8 ? LA_KV_WAVES : (KS 
             else frag_zero<T>(pre[i]);
         }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](Frag<T>(&pre)[NV], T* xs) {
 #pragma unroll
         for (int i = 0; i < NV; i++) {
             const int idx = tid + i * 256, row = idx / LPR, v = idx - row * LPR;
@@ -179,15 +181,31 @@ __global__ __launch_bounds__(256, (KS * (int)sizeof(T) <= 8 ? LA_KV_WAVES : (KS 
             if (idx < TP * LPR) frag_store<T>(pre[i], xs + row * CP + v * 8);
         }
     };
-    if (t_begin < t_end) gload(t_begin);
-    for (int t = t_begin; t < t_end; t++) {
-        __syncthreads();  // previous tile's MFMA reads are done
-        lstore();
-        __syncthreads();
-        if (t + 1 < t_end) gload(t + 1);
-        const int valid = a.n - t * TP;
-        if (valid >= TP) kv_tile<T, KS, WREG, false>(xs, fk, fv, wk, wv, ctx, m_run, ksum, valid, lane);
-        else kv_tile<T, KS, WREG, true>(xs, fk, fv, wk, wv, ctx, m_run, ksum, valid, lane);
+    // Software pipeline, PD tiles deep: a block has PD x 8..16 KB of rows in flight (two blocks per CU), enough to cover the
+    // HBM latency at the CU's share of the bandwidth - with one tile ahead the kernel ran at a third of it.  The LDS tile is
+    // double-buffered, so one barrier per tile suffices (the tile staged at step t is read at step t and rewritten at t + 2).
+    auto step = [&](Frag<T>(&pre)[NV], int t) {
+        if (t < t_end) {  // block-uniform
+            T* xb = xs + ((t - t_begin) & 1) * (TP * CP);
+            lstore(pre, xb);
+            __syncthreads();
+            if (t + PD < t_end) gload(pre, t + PD);
+            const int valid = a.n - t * TP;
+            if (valid >= TP) kv_tile<T, KS, WREG, false>(xb, fk, fv, wk, wv, ctx, m_run, ksum, valid, lane);
+            else kv_tile<T, KS, WREG, true>(xb, fk, fv, wk, wv, ctx, m_run, ksum, valid, lane);
+        }
+    };
+    if (t_begin < t_end) gload(pre0, t_begin);
+    if constexpr (PD > 1) {
+        if (t_begin + 1 < t_end) gload(pre1, t_begin + 1);
+    }
+    if constexpr (PD > 2) {
+        if (t_begin + 2 < t_end) gload(pre2, t_begin + 2);
+    }
+    for (int t = t_begin; t < t_end; t += PD) {
+        step(pre0, t);
+        if constexpr (PD > 1) step(pre1, t + 1);
+        if constexpr (PD > 2) step(pre2, t + 2);
     }
     ksum += __shfl_xor(ksum, 32, 64);
     const size_t slot = ((size_t)b * a.splits + split) * 4 + h;
@@ -394,7 +412,7 @@ __global__ __launch_bounds__(NW * 64, (KS <= 8 ? 2 : 1)) void la_out_kernel(dig_
 
 template <typename T, int KS> int launch_kvctx(const dig_la_kvctx_args* a, hipStream_t st) {
     constexpr int C = KS * 16;
-    const size_t lds = (size_t)64 * (C + 8) * sizeof(T);
+    const size_t lds = (size_t)2 * 64 * (C + 8) * sizeof(T);  // double-buffered pixel tile
     constexpr bool WREG = sizeof(T) == 2 || KS <= 4;  // k/v weight fragments live in registers (fp32 fragments are twice as large)
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)la_kv_ctx_kernel<T, KS, WREG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((la_kv_ctx_kernel<T, KS, WREG>), dim3(a->splits, a->B), dim3(256), lds, st, *a);
