@@ -290,6 +290,149 @@ template <int DH> __global__ __launch_bounds__(256, 1) void vit_attn_mfma_kernel
     }
 }
 
+// ---- the matrix-core path for long token sequences (320 < N <= 928: the reference's VOC-sized inputs, e.g. 368x496 -> 713 patches
+// + 20 class tokens = 733 tokens, infer_DiG.py:91-118) -----------------------------------------------------------------------------
+// Same block = (32-query tile, image) and head loop, but nothing of size N lives in registers and neither the scores nor V of a
+// head are staged in LDS.  Two passes over the 32-key tiles of a head, the tiles dealt round-robin to the four waves:
+//   pass A  S^T = K Q^T (keys down the accumulator registers, queries across the lanes, so a query's running max / sum of
+//           exponentials is lane-local), merged over the 2 lane halves x 4 waves through LDS;
+//   pass B  S^T again, p = exp(s - m) / l in the accumulator registers.  Those registers ARE the A operand of O += P V on
+//           v_mfma_f32_32x32x2_f32 (lane (q, half) supplies P[q][key(e, half)]), the matching V row comes straight from
+//           global/L2 as a coalesced 128-byte read, and p is added into the head-sum [32][N | 1] in LDS (odd pitch: the
+//           32 query rows of one key hit 32 banks; every (q, key) is owned by exactly one lane, so no atomics).
+// The waves' partial O tiles meet in LDS once per head.  fp32 products and accumulation throughout, as in the kernel above.
+constexpr int ATT_T_MAXN = 928;
+template <int DH> __global__ __launch_bounds__(256, 1) void vit_attn_tiled_kernel(dig_vit_attn_args a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int DT = DH / 32, NKS = DH / 16;
+    const int N = a.N, nkt = (N + 31) / 32, PP = N | 1;
+    float* Pacc = sm;                       // [32][PP] sum over the heads of the probabilities
+    float* xb = Pacc + 32 * PP;             // [4 waves][DT][32 q][33] partial O tiles
+    float* ml = xb + 4 * DT * 32 * 33;      // [8 = wave x half][32 q][2] partial (max, sum)
+    float* mfin = ml + 8 * 32 * 2;          // [32 q][2] (max, 1 / sum) of the current head
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, q0 = blockIdx.x * TQM;
+    const int D3 = 3 * a.heads * DH, Dm = a.heads * DH;
+    const float* qkv = a.qkv + (size_t)b * N * D3;
+    const float scale = rsqrtf((float)DH);
+    const int qrow = min(q0 + r, N - 1);  // rows past the end repeat the last query; they are never stored
+    for (int i = tid; i < 32 * PP; i += 256) Pacc[i] = 0.f;
+    auto kload = [&](Frag<float>(&fk)[NKS], int kt, int h) {
+        const int key = min(kt * 32 + r, N - 1);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ks++) frag_load<float>(fk[ks], qkv + (size_t)key * D3 + Dm + h * DH + ks * 16 + hf * 8);
+    };
+    // scaled scores of key tile kt for this lane's query: s[e] belongs to key kt*32 + acc_row(e, lane); -inf past the end
+    auto scores = [&](f32x16& s, const Frag<float>(&fk)[NKS], const Frag<float>(&fq)[NKS], int kt) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) s[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ks++) mma16<float>(s, fk[ks], fq[ks]);
+#pragma unroll
+        for (int e = 0; e < 16; e++) s[e] = (kt * 32 + acc_row(e, lane) < N) ? s[e] * scale : -INFINITY;
+    };
+    for (int h = 0; h < a.heads; h++) {
+        Frag<float> fq[NKS], fk[NKS], fkn[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ks++) frag_load<float>(fq[ks], qkv + (size_t)qrow * D3 + h * DH + ks * 16 + hf * 8);
+        // ---- pass A: per-lane online max / sum over this wave's key tiles
+        float m_run = -INFINITY, l_run = 0.f;
+        if (wave < nkt) kload(fk, wave, h);
+        for (int kt = wave; kt < nkt; kt += 4) {
+            if (kt + 4 < nkt) kload(fkn, kt + 4, h);
+            f32x16 s;
+            scores(s, fk, fq, kt);
+            float tm = s[0];
+#pragma unroll
+            for (int e = 1; e < 16; e++) tm = fmaxf(tm, s[e]);
+            if (tm > m_run) {
+                l_run *= expf(m_run - tm);  // exp(-inf) = 0 on the first tile
+                m_run = tm;
+            }
+            if (m_run > -INFINITY) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) l_run += expf(s[e] - m_run);
+            }
+#pragma unroll
+            for (int ks = 0; ks < NKS; ks++) fk[ks] = fkn[ks];
+        }
+        ml[((wave * 2 + hf) * 32 + r) * 2 + 0] = m_run;
+        ml[((wave * 2 + hf) * 32 + r) * 2 + 1] = l_run;
+        __syncthreads();
+        if (tid < 32) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int p = 0; p < 8; p++) m = fmaxf(m, ml[(p * 32 + tid) * 2]);
+            float l = 0.f;
+#pragma unroll
+            for (int p = 0; p < 8; p++) {
+                const float mp = ml[(p * 32 + tid) * 2];
+                if (mp > -INFINITY) l += ml[(p * 32 + tid) * 2 + 1] * expf(mp - m);
+            }
+            mfin[tid * 2] = m;
+            mfin[tid * 2 + 1] = 1.0f / l;
+        }
+        __syncthreads();
+        const float m = mfin[r * 2], linv = mfin[r * 2 + 1];
+        // ---- pass B: probabilities, head-sum, O += P V
+        f32x16 acc_o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc_o[dt][e] = 0.f;
+        if (wave < nkt) kload(fk, wave, h);
+        for (int kt = wave; kt < nkt; kt += 4) {
+            if (kt + 4 < nkt) kload(fkn, kt + 4, h);
+            float vv[16][DT];  // V[key(e, hf)][dt*32 + r]: in flight under the score MFMAs
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int key = min(kt * 32 + acc_row(e, lane), N - 1);
+#pragma unroll
+                for (int dt = 0; dt < DT; dt++) vv[e][dt] = qkv[(size_t)key * D3 + 2 * Dm + h * DH + dt * 32 + r];
+            }
+            f32x16 s;
+            scores(s, fk, fq, kt);
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int key = kt * 32 + acc_row(e, lane);
+                const float p = expf(s[e] - m) * linv;  // exp(-inf) = 0 for the keys past the end
+                s[e] = p;
+                if (key < N) Pacc[r * PP + key] += p;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+#pragma unroll
+                for (int dt = 0; dt < DT; dt++) acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[e], vv[e][dt], acc_o[dt], 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ks++) fk[ks] = fkn[ks];
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) xb[((wave * DT + dt) * 32 + acc_row(e, lane)) * 33 + r] = acc_o[dt][e];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 32 * DH / 256; i++) {
+            const int idx = tid + i * 256, q = idx / DH, d = idx - q * DH, dt = d >> 5, dd = d & 31;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; w++) v += xb[((w * DT + dt) * 32 + q) * 33 + dd];
+            if (q0 + q < N) a.out[((size_t)b * N + q0 + q) * Dm + h * DH + d] = v;
+        }
+        // the next head writes ml before its first barrier and xb after its second: no barrier needed here
+    }
+    __syncthreads();
+    const float nh = (float)a.heads;
+    for (int i = tid; i < 32 * N; i += 256) {
+        const int qi = i / N, j = i - qi * N, q = q0 + qi;
+        if (q >= N) break;
+        const float mean = Pacc[qi * PP + j] / nh;  // torch.mean over heads (mctformer.py:303)
+        a.acc_all[((size_t)b * N + q) * N + j] += mean;
+        if (a.acc_cls && q < a.ncls) a.acc_cls[((size_t)b * a.ncls + q) * N + j] += mean;
+    }
+}
+
 // ---- bicubic resize of the pos-embed grid -----------------------------------------------------------------
 __device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
 __device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
@@ -430,8 +573,9 @@ extern "C" int dig_vit_attn(const dig_vit_attn_args* a, void* stream_) {
     STREAM;
     DIG_CHECK(a && a->qkv && a->out && a->acc_all, DIG_EINVAL, "vit_attn: null pointer");
     DIG_CHECK(a->B > 0 && a->N > 0 && a->heads > 0 && (a->dh == 64 || a->dh == 32), DIG_EINVAL, "vit_attn: bad shape (head dim must be 32 or 64)");
-    static const bool no_mfma = getenv("DIG_VIT_ATTN_NO_MFMA") != nullptr;  // test hook: keep the VALU kernel
-    if (a->N <= 8 * ATT_MAXE && !no_mfma) {
+    const bool no_mfma = getenv("DIG_VIT_ATTN_NO_MFMA") != nullptr;      // test hooks, read per call: keep the VALU kernel,
+    const bool force_tiled = getenv("DIG_VIT_ATTN_TILED") != nullptr;  // or the long-sequence kernel at any N
+    if (a->N <= 8 * ATT_MAXE && !no_mfma && !force_tiled) {
         const int NP = (a->N + 31) / 32 * 32 + 4;
         size_t vsz = (size_t)(NP - 4) * (a->dh + 1);  // V rows; reused as the 4 x [32][33] partial-sum exchange of P V
         if (vsz < 4 * 32 * 33) vsz = 4 * 32 * 33;
@@ -446,6 +590,22 @@ extern "C" int dig_vit_attn(const dig_vit_attn_args* a, void* stream_) {
             if (e == hipSuccess) hipLaunchKernelGGL(vit_attn_mfma_kernel<32>, gridm, dim3(256), ldsm, stream, *a);
         }
         DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "vit_attn: cannot raise dynamic LDS to %zu: %s", ldsm, hipGetErrorString(e));
+        DIG_LAUNCH_CHECK("vit_attn");
+        return DIG_OK;
+    }
+    if (a->N <= ATT_T_MAXN && !no_mfma) {
+        const int DT = a->dh / 32;
+        const size_t ldst = ((size_t)32 * (a->N | 1) + 4 * DT * 32 * 33 + 8 * 32 * 2 + 32 * 2) * sizeof(float);
+        const dim3 gridt(cdiv(a->N, TQM), a->B);
+        hipError_t e = hipSuccess;
+        if (a->dh == 64) {
+            e = hipFuncSetAttribute((const void*)vit_attn_tiled_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst);
+            if (e == hipSuccess) hipLaunchKernelGGL(vit_attn_tiled_kernel<64>, gridt, dim3(256), ldst, stream, *a);
+        } else {
+            e = hipFuncSetAttribute((const void*)vit_attn_tiled_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst);
+            if (e == hipSuccess) hipLaunchKernelGGL(vit_attn_tiled_kernel<32>, gridt, dim3(256), ldst, stream, *a);
+        }
+        DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "vit_attn: cannot raise dynamic LDS to %zu: %s", ldst, hipGetErrorString(e));
         DIG_LAUNCH_CHECK("vit_attn");
         return DIG_OK;
     }

@@ -117,6 +117,40 @@ def test_cam_multiscale_flip_c80_vs_oracle(scale):
     assert np.array_equal(lab, O.cam_argmax_labels(cam.cam_dict(got[0], label[0]), 0.45, C + 1))
 
 
+def test_cam_voc_sized_input_vs_oracle():
+    """A VOC-sized input, 368x496 (713 patches + 20 class tokens = 733 tokens), the size class the reference's inference
+    loop feeds (infer_DiG.py:91-118): the attention runs on the key-tiled matrix-core kernel (dig_vit_attn, 320 < N <= 928).
+    rcams / normalised CAMs against the CPU oracle (1e-4); the uint8 label maps against the oracle's argmax of the ORACLE's
+    CAMs, bit-exact at every pixel whose top-2 margin in the oracle is >= 1e-5 (183 k pixels; the handful below that margin
+    are counted and printed, with seed 41 one of three flips), and bit-exact everywhere against numpy's argmax of the device CAMs."""
+    C, H, W = 20, 368, 496
+    m = make_mct(C)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    img = synth.synth_imagenet_images(1, H, W, seed=41)
+    label = synth.synth_labels(1, C, seed=3)
+    ref_rc = O.mctformer_cam(sd, img, 12)
+    got_rc = m(img.to(DEV), return_att=True, n_layers=12)
+    assert float((got_rc.cpu() - ref_rc).abs().max()) <= 1e-4 * max(1.0, float(ref_rc.abs().max()))
+    ref = O.infer_multi_cam(sd, img, label, 12)
+    got = cam.infer_multi_cam(m, img.to(DEV), label.to(DEV), 12)
+    assert got.shape == (1, C, H, W)
+    assert float((got.cpu() - ref).abs().max()) <= 1e-4
+    for thr in (0.35, 0.45):
+        lab = cam.cam_labels(got, label.to(DEV), thr)[0].cpu().numpy()
+        ref_lab = O.cam_argmax_labels(cam.cam_dict(ref[0], label[0]), thr, C + 1)
+        nc = ref[0].numpy()
+        stack = np.concatenate([np.full((1, H, W), thr, np.float32), nc * (label[0].numpy()[:, None, None] > 1e-5)])
+        top2 = np.sort(stack, axis=0)[-2:]
+        near = (top2[1] - top2[0]) < 1e-5
+        mism = lab != ref_lab
+        print("voc368x496 thr", thr, "label mismatches", int(mism.sum()), "near-tie pixels (<1e-5)", int(near.sum()))
+        # the oracle's CAMs and the device's differ by fp32 reassociation (<= 1e-4 above, ~1e-6 typical): a label may differ
+        # only where the oracle's own top-2 margin is below 1e-5; everywhere else the map is bit-exact
+        assert not (mism & ~near).any()
+        # and on the SAME CAMs the device argmax is bit-exact against the reference's numpy formulation
+        assert np.array_equal(lab, O.cam_argmax_labels(cam.cam_dict(got[0], label[0]), thr, C + 1))
+
+
 @pytest.mark.parametrize("name,hd", [("lfca224_c20", 14), ("lfca224_c20_maps16", 16)])
 def test_lfca_consumer_vs_reference_golden(golden, name, hd):
     """SURVEY 8f-1, the step right after the guidance maps: MCTformerV2_DiG.forward(x, feat_diff=[5 x [B,1024,h,w]]) in eval

@@ -404,12 +404,19 @@ def test_lfca_helper_kernels(dt):
         assert (nchw(out) - ref).abs().max() <= (1e-5 if dt == torch.float32 else tol(dt, ref)), (ho, wo)
 
 
-@pytest.mark.parametrize("cfg", [(2, 36, 3, 64), (1, 216, 6, 64), (2, 100, 2, 32), (1, 330, 2, 64), (3, 7, 1, 32)])
-def test_vit_attn_rollout(cfg):
+@pytest.mark.parametrize("cfg", [(2, 36, 3, 64, ""), (1, 216, 6, 64, ""), (2, 100, 2, 32, ""), (1, 330, 2, 64, ""), (3, 7, 1, 32, ""),
+                                 (1, 733, 6, 64, ""), (2, 520, 3, 32, ""), (1, 928, 1, 64, ""), (1, 940, 1, 32, ""),
+                                 (2, 36, 3, 64, "TILED"), (3, 7, 1, 32, "TILED"), (1, 97, 2, 64, "TILED"), (1, 128, 2, 32, "TILED"),
+                                 (1, 330, 2, 64, "NO_MFMA")])
+def test_vit_attn_rollout(cfg, monkeypatch):
     """dig_vit_attn (vision_transformer.py:87-103 + the head-mean / layer-sum of mctformer.py:302-315): output tokens and the
-    two probability accumulators against torch, over two layers.  N <= 320 runs on the fp32 matrix cores, N = 330 on the VALU
-    kernel; ragged token counts, both head widths."""
-    B, N, heads, dh = cfg
+    two probability accumulators against torch, over two layers.  N <= 320 runs on the register-resident fp32 matrix-core
+    kernel, 320 < N <= 928 (733 = the reference's 368x496 VOC crop with 20 class tokens) on the key-tiled one, beyond that the
+    VALU kernel; ragged token counts, both head widths; the env hooks force the tiled / VALU kernels at small N (fewer key
+    tiles than waves, a last tile with one key)."""
+    B, N, heads, dh, hook = cfg
+    if hook:
+        monkeypatch.setenv("DIG_VIT_ATTN_" + hook, "1")
     ncls, D = min(5, N), heads * dh
     acc_all = torch.zeros(B, N, N, device=DEV)
     acc_cls = torch.zeros(B, ncls, N, device=DEV)
