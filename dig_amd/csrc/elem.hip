@@ -211,6 +211,29 @@ __global__ void sched_axpby_kernel(dig_sched_axpby_args a) {
     }
 }
 
+// one DDIM update for objective pred_v (see dig_hip.h); mul_rn keeps each product a separately rounded fp32 value
+__device__ __forceinline__ float mul_rn(float a, float b) {
+    float p = a * b;
+    asm volatile("" : "+v"(p));
+    return p;
+}
+__global__ void ddim_step_kernel(dig_ddim_step_args a) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)a.n; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = a.x[i];
+        float x0 = axpby_rn(a.sqrt_ac, x, -a.sqrt_1mac, a.v[i]);
+        x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        float o = x0;
+        if (!a.last) {
+            const float eps = (mul_rn(a.sqrt_recip, x) - x0) / a.sqrt_recipm1;
+            float s = mul_rn(x0, a.sqrt_alpha_next) + mul_rn(a.c, eps);
+            asm volatile("" : "+v"(s));
+            o = a.noise ? s + mul_rn(a.sigma, a.noise[i]) : s;
+        }
+        a.out[i] = o;
+        if (a.out_unnorm) a.out_unnorm[i] = (o + 1.f) * 0.5f;
+    }
+}
+
 template <typename T> __global__ void sinusoid_kernel(dig_sinusoid_args a) {
     const int half = a.dim / 2;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -361,6 +384,17 @@ extern "C" int dig_row_max(const dig_row_max_args* a, void* stream_) {
     if (a->dtype == DIG_BF16) hipLaunchKernelGGL(row_max_kernel<bf16>, dim3((unsigned)a->rows), dim3(256), 0, stream, *a);
     else hipLaunchKernelGGL(row_max_kernel<float>, dim3((unsigned)a->rows), dim3(256), 0, stream, *a);
     DIG_LAUNCH_CHECK("row_max");
+    return DIG_OK;
+}
+
+extern "C" int dig_ddim_step(const dig_ddim_step_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->x && a->v && a->out, DIG_EINVAL, "ddim_step: null pointer");
+    DIG_CHECK(a->n > 0, DIG_EINVAL, "ddim_step: bad size n=%lld", a->n);
+    DIG_CHECK(a->last || a->noise || a->sigma == 0.f, DIG_EINVAL, "ddim_step: sigma=%g needs a noise tensor", (double)a->sigma);
+    DIG_CHECK(a->last || a->sqrt_recipm1 > 0.f, DIG_EINVAL, "ddim_step: sqrt_recipm1_alphas_cumprod must be positive");
+    hipLaunchKernelGGL(ddim_step_kernel, dim3(grid_for((size_t)a->n, 256)), dim3(256), 0, stream, *a);
+    DIG_LAUNCH_CHECK("ddim_step");
     return DIG_OK;
 }
 

@@ -517,8 +517,9 @@ def sigmoid_beta_schedule(timesteps, start=-3, end=3, tau=1):
 
 class GaussianDiffusion(nn.Module):
     """ddp.py:493-634, 853-913 - the subset DiG calls (model.py:132-143, 288, 302-306): schedule buffers with the
-    reference's names, normalize/unnormalize, q_sample, p_losses (eval branch), predict_start_from_v.
-    Samplers and the training loss are outside the guidance path and are not provided."""
+    reference's names, normalize/unnormalize, q_sample, p_losses (eval branch), predict_start_from_v, and the truncated
+    DDIM sampler sample_from_t / ddim_sample_from_t (ddp.py:770-831).  The ancestral samplers and the training loss are
+    outside the guidance path and are not provided."""
 
     def __init__(self, model, *, image_size, timesteps=1000, sampling_timesteps=None, objective='pred_v',
                  beta_schedule='sigmoid', schedule_fn_kwargs=dict(), ddim_sampling_eta=0., auto_normalize=True,
@@ -594,6 +595,89 @@ class GaussianDiffusion(nn.Module):
     def predict_start_from_v(self, x_t, t, v):
         """ddp.py:630-634."""
         return self._axpby(x_t, v, t, -1.0)
+
+    def ddim_time_pairs(self, num_step):
+        """ddp.py:775-782: (time, time_next) pairs of the DDIM schedule truncated at num_step; the last pair ends at -1."""
+        slice_idx = int((num_step / self.num_timesteps) * self.sampling_timesteps)
+        times = torch.linspace(-1, self.num_timesteps - 1, steps=self.sampling_timesteps + 1)[:slice_idx]
+        times = list(reversed(times.int().tolist()))
+        return list(zip(times[:-1], times[1:]))
+
+    @torch.no_grad()
+    def ddim_sample_from_t(self, shape, img, num_step, return_all_timesteps=False, noise=None):
+        """ddp.py:770-819: q_sample `img` to timestep num_step, then DDIM back to t = 0 with clip_x_start and the re-derived
+        noise prediction (ddp.py:645-668, 'pred_v').  Each step is one Unet forward on the HIP kernels + one dig_ddim_step
+        launch; the step's schedule scalars are formed on the host in fp32 from a host copy of alphas_cumprod exactly as
+        the reference forms them from its 0-dim tensors.  `noise` (optional) is the q_sample noise the reference draws
+        (ddp.py:856); per-step noise is drawn only when ddim_sampling_eta > 0 (with eta = 0 the reference multiplies it by 0)."""
+        if self.model.training:
+            raise NotImplementedError("sampling runs the forward-only Unet; call .eval() first")
+        if not img.is_cuda:
+            raise RuntimeError("dig_amd.GaussianDiffusion runs on the HIP device only (no CPU fallback)")
+        B = shape[0]
+        assert tuple(img.shape) == tuple(shape), (tuple(img.shape), tuple(shape))
+        if not 0 <= int(num_step) < self.num_timesteps:
+            raise IndexError(f"timestep out of range: num_step must lie in [0, {self.num_timesteps}), got {num_step}")
+        pairs = self.ddim_time_pairs(num_step)
+        dev = img.device
+        tab = {k: getattr(self, k).detach().cpu() for k in ("alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+                                                             "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod")}
+        eta = self.ddim_sampling_eta
+        t0 = _mark_t_checked(torch.full((B,), int(num_step), device=dev, dtype=torch.long), self.num_timesteps)
+        x = self.q_sample(img, t0, noise)
+        stack = None
+        if return_all_timesteps:
+            stack = torch.empty(B, len(pairs) + 1, *img.shape[1:], dtype=torch.float32, device=dev)
+            stack[:, 0].copy_(self._unnorm_copy(x))
+        out_u = None
+        for k, (time, time_next) in enumerate(pairs):
+            tc = _mark_t_checked(torch.full((B,), time, device=dev, dtype=torch.long), self.num_timesteps)
+            v, _, _ = _unet_forward(self.model, x, None, tc, None, None, (1.0,) * 3, (0.0,) * 3, want_xt=False)
+            last = time_next < 0
+            san = c = sigma = 0.0
+            nz = None
+            if not last:
+                alpha, alpha_next = tab["alphas_cumprod"][time], tab["alphas_cumprod"][time_next]
+                sg = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+                san, c, sigma = float(alpha_next.sqrt()), float((1 - alpha_next - sg ** 2).sqrt()), float(sg)
+                if sigma != 0.0:
+                    nz = torch.randn_like(x)
+            nxt = torch.empty_like(x)
+            final = k == len(pairs) - 1
+            if stack is not None:
+                out_u = torch.empty_like(x)
+            elif final:
+                out_u = torch.empty_like(x) if self.auto_normalize else None
+            call("ddim_step", x=x, v=v.contiguous(), noise=nz, out=nxt, out_unnorm=out_u if self.auto_normalize else None,
+                 sqrt_ac=float(tab["sqrt_alphas_cumprod"][time]), sqrt_1mac=float(tab["sqrt_one_minus_alphas_cumprod"][time]),
+                 sqrt_recip=float(tab["sqrt_recip_alphas_cumprod"][time]), sqrt_recipm1=float(tab["sqrt_recipm1_alphas_cumprod"][time]),
+                 sqrt_alpha_next=san, c=c, sigma=sigma, last=int(last), n=x.numel())
+            x = nxt
+            if stack is not None:
+                stack[:, k + 1].copy_(out_u if self.auto_normalize else x)
+        if stack is not None:
+            return stack
+        if not pairs:
+            return self._unnorm_copy(x)
+        return out_u if self.auto_normalize else x
+
+    def _unnorm_copy(self, x):
+        """unnormalize() of a device tensor through dig_sched_axpby's post-affine: 0.5 * (1 * x + 0 * x) + 0.5."""
+        if not self.auto_normalize:
+            return x.clone()
+        t = _mark_t_checked(torch.zeros(x.shape[0], device=x.device, dtype=torch.long), self.num_timesteps)
+        out = torch.empty_like(x)
+        P = self.model.packed()
+        call("sched_axpby", x=x, y=x, t=t, sqrt_ac=P["one"], sqrt_1mac=P["zero"], out=out, post_scale=(0.5,) * 3,
+             post_shift=(0.5,) * 3, sign=1.0, B=x.shape[0], HW=x.shape[2] * x.shape[3])
+        return out
+
+    def sample_from_t(self, batch_size=16, img=None, step=None, return_all_timesteps=False, noise=None):
+        """ddp.py:827-831.  Only the DDIM branch (sampling_timesteps < timesteps, the DiG configuration, model.py:135) is built."""
+        if not self.is_ddim_sampling:
+            raise NotImplementedError("p_sample_loop_from_t (ancestral sampling) is not built; construct with sampling_timesteps < timesteps")
+        return self.ddim_sample_from_t((batch_size, self.channels, self.image_size, self.image_size), img, step,
+                                       return_all_timesteps=return_all_timesteps, noise=noise)
 
     def p_losses(self, x_start, t, noise=None, offset_noise_strength=None, pre_scale=(1.0,) * 3, pre_shift=(0.0,) * 3):
         """Eval branch of ddp.py:862-913: returns (x_t, model_out, feat_out).  The discarded MSE of the reference

@@ -299,6 +299,25 @@ typedef struct {
 } dig_sched_axpby_args;
 int dig_sched_axpby(const dig_sched_axpby_args* a, void* stream);
 
+/* One DDIM update of ddim_sample_from_t (ddp.py:792-814) for objective 'pred_v', elementwise over n fp32 values:
+ *   x0  = clamp(sqrt_ac*x - sqrt_1mac*v, -1, 1)                      model_predictions, clip_x_start=True (ddp.py:662-666,630-634)
+ *   eps = (sqrt_recip*x - x0) / sqrt_recipm1                         predict_noise_from_start (ddp.py:618-622)
+ *   out = last ? x0 : x0*sqrt_alpha_next + c*eps + sigma*noise       (ddp.py:797-812; noise may be NULL when sigma == 0)
+ * every product, sum and the division rounded separately, as the reference's tensor expression evaluates them.
+ * The schedule coefficients are the caller's host scalars for this step's (time, time_next).
+ * out_unnorm (nullable) also receives unnormalize(out) = (out + 1) * 0.5 (ddp.py:818, normalize_to_neg_one_to_one's inverse). */
+typedef struct {
+    const float* x;
+    const float* v;
+    const float* noise;
+    float* out;
+    float* out_unnorm;
+    float sqrt_ac, sqrt_1mac, sqrt_recip, sqrt_recipm1, sqrt_alpha_next, c, sigma;
+    int last;
+    long long n;
+} dig_ddim_step_args;
+int dig_ddim_step(const dig_ddim_step_args* a, void* stream);
+
 /* SinusoidalPosEmb (ddp.py:118-130): out[b][0..dim) fp32 = [sin(t*w_i), cos(t*w_i)] stored as dtype */
 typedef struct {
     const long long* t;

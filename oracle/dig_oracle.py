@@ -247,6 +247,42 @@ def p_losses_eval(sd, x_start, t, noise):
     return x_t, v, feats
 
 
+def ddim_time_pairs(num_step, total_timesteps=1000, sampling_timesteps=150):
+    """ddp.py:775-782: the (time, time_next) pairs of the truncated DDIM schedule, last pair ends at -1."""
+    slice_idx = int((num_step / total_timesteps) * sampling_timesteps)
+    times = torch.linspace(-1, total_timesteps - 1, steps=sampling_timesteps + 1)[:slice_idx]
+    times = list(reversed(times.int().tolist()))
+    return list(zip(times[:-1], times[1:]))
+
+
+def ddim_sample_from_t(sd, img, num_step, noise, sampling_timesteps=150, eta=0.0, step_noises=None):
+    """GaussianDiffusion.ddim_sample_from_t(..., return_all_timesteps=True), ddp.py:770-819, objective pred_v:
+    q_sample to num_step with the explicit `noise` (the reference draws it, ddp.py:785,856), then the DDIM updates with
+    clip_x_start / rederive_pred_noise (ddp.py:645-668).  With eta = 0 the per-step noise is multiplied by sigma = 0.
+    Returns the unnormalised stack [B, steps + 1, 3, H, W]."""
+    B = img.shape[0]
+    T = sd["betas"].shape[0]
+    ac = sd["alphas_cumprod"]
+    x = q_sample(sd, img, torch.full((B,), num_step, dtype=torch.long), noise)
+    imgs = [x]
+    for k, (time, time_next) in enumerate(ddim_time_pairs(num_step, T, sampling_timesteps)):
+        t = torch.full((B,), time, dtype=torch.long)
+        v, _ = unet_forward(_sub(sd, "model."), x, t)
+        x0 = predict_start_from_v(sd, x, t, v).clamp(-1.0, 1.0)
+        eps = ((_gather(sd["sqrt_recip_alphas_cumprod"], t, x.dim()) * x - x0)
+               / _gather(sd["sqrt_recipm1_alphas_cumprod"], t, x.dim()))
+        if time_next < 0:
+            x = x0
+        else:
+            alpha, alpha_next = ac[time], ac[time_next]
+            sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+            c = (1 - alpha_next - sigma ** 2).sqrt()
+            nz = step_noises[k] if step_noises is not None else torch.zeros_like(x)
+            x = x0 * alpha_next.sqrt() + c * eps + sigma * nz
+        imgs.append(x)
+    return (torch.stack(imgs, dim=1) + 1) * 0.5
+
+
 # --------------------------------------------------------------------------------------
 # guidance-extraction glue  (models/model_ECCV24_DiG.py:286-316, 499-519)
 # --------------------------------------------------------------------------------------

@@ -11,6 +11,7 @@ oracle/ref_import.py with off-path dependency stubs).  For every case it
 Usage:  python oracle/gen_golden.py            (rewrites tests/golden/)
         python oracle/gen_golden.py lfca       (only the LFCA cases; merges into MANIFEST.json)
         python oracle/gen_golden.py keys       (only tests/golden/state_dict_keys.json)
+        python oracle/gen_golden.py ddim       (only the ddim_sample_from_t cases)
 """
 import json
 import os
@@ -228,6 +229,35 @@ def case_lfca(mct, name, C, H, W, hd, wd):
     save(name, cam_diff=outs["cam_diff"], diff_cls=outs["diff_cls"], diff_pcls=outs["diff_pcls"], rcams=outs["rcams"])
 
 
+def case_ddim(ddp, name, dim, H, W, B, num_step, seed=4242):
+    """(f)-2: GaussianDiffusion.sample_from_t -> ddim_sample_from_t (ddp.py:770-819, 827-831), eta = 0, on CPU.
+    The method moves its timestep tensor with a hard-coded `.cuda()` (ddp.py:785); here, and only here, Tensor.cuda is
+    patched to the identity so the reference's own code runs on the CPU.  The q_sample noise it draws (ddp.py:856) is
+    recovered by re-seeding: it is the first randn_like after the seed."""
+    gd = ref_diffusion(ddp, dim, H)
+    assert gd.is_ddim_sampling and gd.ddim_sampling_eta == 0.0
+    sd = {k: v.clone() for k, v in gd.state_dict().items()}
+    img = gd.normalize(synth.synth_images(B, H, W, seed=1234))
+    torch.manual_seed(seed)
+    noise = torch.randn_like(img)
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        torch.manual_seed(seed)
+        stack = gd.sample_from_t(batch_size=B, img=img.clone(), step=num_step, return_all_timesteps=True)
+        torch.manual_seed(seed)
+        final = gd.sample_from_t(batch_size=B, img=img.clone(), step=num_step)
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    assert torch.equal(final, stack[:, -1])
+    ostack = O.ddim_sample_from_t(sd, img, num_step, noise, sampling_timesteps=gd.sampling_timesteps)
+    pairs = O.ddim_time_pairs(num_step, gd.num_timesteps, gd.sampling_timesteps)
+    assert stack.shape == ostack.shape == (B, len(pairs) + 1, 3, H, W), (stack.shape, ostack.shape)
+    record(name, x_T=maxabs(stack[:, 0], ostack[:, 0]), mid=maxabs(stack[:, len(pairs) // 2], ostack[:, len(pairs) // 2]),
+           final=maxabs(stack[:, -1], ostack[:, -1]), all=maxabs(stack, ostack))
+    save(name, img=img, noise=noise, num_step=np.int64(num_step), times=np.array(pairs, np.int64), stack=stack)
+
+
 def synth_eval_set(C=20, seed=5):
     """Small synthetic CAM dicts + ground-truth maps (with 255 boundary pixels) for the evaluation cases."""
     rng = np.random.RandomState(seed)
@@ -321,6 +351,12 @@ def main():
     if sys.argv[1:] == ["keys"]:
         case_state_dict_keys(ref_import.load_ddp(), mct)
         return
+    if sys.argv[1:] == ["ddim"]:
+        ddp = ref_import.load_ddp()
+        case_ddim(ddp, "ddim_tiny32_t100", 16, 32, 32, 2, 100)
+        case_ddim(ddp, "ddim64_t60", 64, 64, 64, 1, 60)
+        _merge_manifest()
+        return
     if sys.argv[1:] == ["eval"]:
         case_eval(ref_import.load_evaluation())
         _merge_manifest()
@@ -338,6 +374,8 @@ def main():
     case_lfca(mct, "lfca224_c20", 20, 224, 224, 14, 14)
     case_lfca(mct, "lfca224_c20_maps16", 20, 224, 224, 16, 16)  # guidance maps from a 256x256 diffusion input: bilinear 14 -> 16
     case_eval(ref_import.load_evaluation())
+    case_ddim(ddp, "ddim_tiny32_t100", 16, 32, 32, 2, 100)
+    case_ddim(ddp, "ddim64_t60", 64, 64, 64, 1, 60)
     case_state_dict_keys(ddp, mct)
     with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
         json.dump({"generator": "oracle/gen_golden.py", "torch": torch.__version__,

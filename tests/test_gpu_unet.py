@@ -258,3 +258,35 @@ def test_linear_attention_widths(dt, tl, C, H, W, B):
     ref = O.linear_attention(w, xq) + xq
     y = D._linear_attention(_pack_la(la, dt), nhwc(x, dt))
     assert (nchw(y) - ref).abs().max() <= tl * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("name,dim,H,B,num_step", [("ddim_tiny32_t100", 16, 32, 2, 100), ("ddim64_t60", 64, 64, 1, 60)])
+def test_ddim_sample_from_t_vs_reference_golden(golden, name, dim, H, B, num_step):
+    """GaussianDiffusion.sample_from_t -> ddim_sample_from_t (ddp.py:770-831, eta = 0): the fixture is the reference's own
+    output stack (oracle/gen_golden.py case_ddim).  fp32 compute: every image of the trajectory within 1e-5 (14 / 8 chained
+    Unet passes, observed 5e-7; the first image, q_sample + unnormalize, bit-exact); bf16 compute: 1e-2 on the final image
+    (values in [0, 1], observed 3.2e-3).  The step times match the
+    fixture exactly, and the final-only call returns the last image of the stack bit for bit."""
+    g = golden(name)
+    u = D.Unet(dim=dim, dim_mults=(1, 2, 4, 8), flash_attn=True)
+    synth.fill_state_dict(u, seed=0)
+    gd = D.GaussianDiffusion(u, image_size=H, timesteps=1000, sampling_timesteps=150).to(DEV).eval()
+    assert np.array_equal(np.array(gd.ddim_time_pairs(num_step), np.int64), g["times"])
+    img, noise = T(g["img"]).to(DEV), T(g["noise"]).to(DEV)
+    ref = T(g["stack"])
+    u.set_compute_dtype(torch.float32)
+    stack = gd.sample_from_t(batch_size=B, img=img, step=num_step, return_all_timesteps=True, noise=noise)
+    assert stack.shape == ref.shape
+    assert torch.equal(stack[:, 0].cpu(), ref[:, 0])  # q_sample + unnormalize: bit-exact
+    errs = [float((stack[:, k].cpu() - ref[:, k]).abs().max()) for k in range(ref.shape[1])]
+    print(name, "fp32 per-step max-abs", ["%.1e" % e for e in errs])
+    assert max(errs) <= 1e-5
+    final = gd.sample_from_t(batch_size=B, img=img, step=num_step, noise=noise)
+    assert torch.equal(final, stack[:, -1])
+    u.set_compute_dtype(torch.bfloat16)
+    fb = gd.sample_from_t(batch_size=B, img=img, step=num_step, noise=noise)
+    eb = float((fb.cpu() - ref[:, -1]).abs().max())
+    print(name, "bf16 final max-abs", eb)
+    assert eb <= 1e-2
+    with pytest.raises(IndexError):
+        gd.sample_from_t(batch_size=B, img=img, step=1000)

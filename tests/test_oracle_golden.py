@@ -89,6 +89,17 @@ def test_guidance_loop(golden):
     assert (img_diff - T(g["img_diff"])).abs().max() <= TOL
 
 
+def test_ddim_sample_from_t(golden):
+    """ddp.py:770-831 (eta = 0): the oracle's trajectory against the reference's own output stack, tiny Unet, 14 DDIM steps."""
+    g = golden("ddim_tiny32_t100")
+    sd = unet_sd(16, 32)
+    pairs = O.ddim_time_pairs(int(g["num_step"]))
+    assert np.array_equal(np.array(pairs, np.int64), g["times"]) and pairs[-1][1] == -1
+    stack = O.ddim_sample_from_t(sd, T(g["img"]), int(g["num_step"]), T(g["noise"]))
+    assert stack.shape == g["stack"].shape
+    assert (stack - T(g["stack"])).abs().max() <= TOL
+
+
 def _cam_sd(C):
     m = create_model("deit_small_MCTformerV2_DiG", pretrained=False, num_classes=C, lfca=False)
     synth.fill_state_dict(m, seed=0, skip_prefixes=("LFCA", "diff_head_p", "norm."))
