@@ -230,11 +230,13 @@ def mctformer_forward(m, img, n_layers=12, feat_diff=None):
     cams = torch.empty_like(mtatt)
     rcams = torch.empty_like(mtatt)
     call("cam_fuse", acc_all=acc_all, acc_cls=acc_cls, head=head, mtatt=mtatt, cams=cams, rcams=rcams, B=B, C=C, P=Pn)
-    relu_head = head.permute(0, 3, 1, 2).clamp_min(0)
-    k = min(3, Pn)
-    hv = head.permute(0, 3, 1, 2).reshape(B, C, -1)
-    pcls = hv.clamp_min(0).topk(k, dim=-1)[0].mean(-1) - (-hv).clamp_min(0).topk(k, dim=-1)[0].mean(-1)  # mctformer.py:300
-    outs = {"cls": x[:, :C].mean(-1), "pcls": pcls, "cams": relu_head, "fcams": cams, "attn": acc_all[:, C:, C:],
+    # outputs['cams'] = relu(head) as NCHW and the top-3 pooled patch logits (mctformer.py:296-300); class-token logits (:295)
+    relu_head = torch.empty(B, C, hp, wp, dtype=F32, device=dev)
+    pcls = torch.empty(B, C, dtype=F32, device=dev)
+    call("head_pool", **{"in": head}, relu_nchw=relu_head, pooled=pcls, B=B, P=Pn, C=C)
+    cls = torch.empty(B, C, dtype=F32, device=dev)
+    call("row_mean", x0=x, x1=None, out=cls, bstride0=N * D, bstride1=0, B=B, C=C, D=D)
+    outs = {"cls": cls, "pcls": pcls, "cams": relu_head, "fcams": cams, "attn": acc_all[:, C:, C:],
             "mtatt": mtatt, "rcams": rcams, "feat": x[:, C:].reshape(B, hp, wp, D).permute(0, 3, 1, 2)}
     if feat_diff is not None:
         PL = _pack_lfca(m)
@@ -245,14 +247,14 @@ def mctformer_forward(m, img, n_layers=12, feat_diff=None):
         c0, p0 = lfca_forward(PL["LFCA0"], qkv_last[1], C, feat)   # query0 = q of the last block (mctformer.py:280)
         c1, p1 = lfca_forward(PL["LFCA1"], qkv_last[0], C, feat)   # query1 = q of the one before
         out_p = _affine(p0, res=p1, xs=0.5, rs=0.5)                # (p0 + p1) / 2 (mctformer.py:287)
-        out_c = (c0 + c1) / 2
         hh = _affine(ops.conv3x3(out_p, PL["head0"], want_stats=False)[0], pre=2)
-        cd = ops.nhwc_to_nchw_f32(ops.linear_rows(hh, PL["head2"][0], bias=PL["head2"][1], out_f32=True))  # [B,20,hd,wd], pre-ReLU
-        cv = cd.reshape(B, cd.shape[1], -1)
-        kk = min(3, cv.shape[-1])
-        outs["cam_diff"] = cd.clamp_min(0)
-        outs["diff_cls"] = out_c.mean(-1)
-        outs["diff_pcls"] = cv.clamp_min(0).topk(kk, dim=-1)[0].mean(-1) - (-cv).clamp_min(0).topk(kk, dim=-1)[0].mean(-1)
+        h2 = ops.linear_rows(hh, PL["head2"][0], bias=PL["head2"][1], out_f32=True)  # NHWC [B,hd,wd,C], pre-ReLU
+        Cd = h2.shape[-1]
+        outs["cam_diff"] = torch.empty(B, Cd, hd, wd, dtype=F32, device=dev)
+        outs["diff_pcls"] = torch.empty(B, Cd, dtype=F32, device=dev)
+        call("head_pool", **{"in": h2}, relu_nchw=outs["cam_diff"], pooled=outs["diff_pcls"], B=B, P=hd * wd, C=Cd)
+        outs["diff_cls"] = torch.empty(B, C, dtype=F32, device=dev)  # ((c0 + c1) / 2).mean(-1) (mctformer.py:288,340)
+        call("row_mean", x0=c0, x1=c1, out=outs["diff_cls"], bstride0=C * D, bstride1=C * D, B=B, C=C, D=D)
     return outs
 
 

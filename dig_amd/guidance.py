@@ -59,7 +59,8 @@ def update_forward(diffusion, net_trm, img, noises=None, n_layers=12):
     """The forward computations of model_WSSS.update (models/model_ECCV24_DiG.py:286-322,396-404), inference mode:
     guidance maps at t = 0..4 and the t = 100 reconstruction from the diffusion Unet, the MCTformer pass that consumes the
     maps through LFCA0/LFCA1 (`net_trm(img, feat_diff_list)`), and the second MCTformer pass on the reconstruction
-    (`net_trm(img_diff)`).  The losses and the optimiser step that follow in the reference are outside this build.
+    (`net_trm(img_diff)`).  The loss terms that follow (model.py:337-421) are dig_amd.losses.update_losses(outputs,
+    outputs_diff, label, ...); the backward pass and the optimiser step (model.py:424-425) are outside this build.
     Returns (outputs, outputs_diff, feat_diff_list, img_diff)."""
     feat_diff_list, img_diff = extract_guidance(diffusion, img, noises)
     outputs = net_trm(img, feat_diff=feat_diff_list, n_layers=n_layers)

@@ -299,6 +299,72 @@ typedef struct {
 } dig_sched_axpby_args;
 int dig_sched_axpby(const dig_sched_axpby_args* a, void* stream);
 
+/* ---- heads and forward losses around the MCTformer passes of model_WSSS.update (models/model_ECCV24_DiG.py:324-421) ---- */
+
+/* in: NHWC fp32 head map [B][P][C].  relu_nchw (nullable) [B][C][P] = relu(in) transposed (outputs['cams'] / ['cam_diff'],
+ * mctformer.py:298,336-339); pooled (nullable) [B][C] = mean(topk(relu(v),k)) - mean(topk(relu(-v),k)), k = min(3,P)
+ * (the patch logits 'pcls' / 'diff_pcls', mctformer.py:300,341). */
+typedef struct {
+    const float* in;
+    float* relu_nchw;
+    float* pooled;
+    int B, P, C;
+} dig_head_pool_args;
+int dig_head_pool(const dig_head_pool_args* a, void* stream);
+
+/* out[b][c] = mean_d( x1 ? (x0[b][c][d] + x1[b][c][d]) / 2 : x0[b][c][d] ); image b of x0/x1 starts at b*bstride floats
+ * (the class-token logits 'cls' = x[:, :C].mean(-1), mctformer.py:295, and 'diff_cls' of the two LFCA outputs, :287-288) */
+typedef struct {
+    const float* x0;
+    const float* x1;
+    float* out;
+    long long bstride0, bstride1;
+    int B, C, D;
+} dig_row_mean_args;
+int dig_row_mean(const dig_row_mean_args* a, void* stream);
+
+/* out[0] (+)= scale * F.multilabel_soft_margin_loss(x, y), x / y [B][C] fp32 (model.py:337-340,358-359,406-409) */
+typedef struct {
+    const float* x;
+    const float* y;
+    float* out;
+    float scale;
+    int accumulate, B, C;
+} dig_msm_loss_args;
+int dig_msm_loss(const dig_msm_loss_args* a, void* stream);
+
+/* out[0] (+)= scale * KLDivLoss(reduction='batchmean', log_target=True)(log cat(S, 1-S), log cat(Tt, 1-Tt)) with
+ * S = softmax(student / T, 1), Tt = softmax(teacher / T, 1), [B][C] fp32 (model.py:347-355,360-361) */
+typedef struct {
+    const float* student;
+    const float* teacher;
+    float* out;
+    float T, scale;
+    int accumulate, B, C;
+} dig_kd_bin_loss_args;
+int dig_kd_bin_loss(const dig_kd_bin_loss_args* a, void* stream);
+
+/* partial[b*C+c] = sum_hw | (max_norm(a)[b][c] * (a_times_label ? label : 1) - max_norm(resize(b))[b][c]) * label[b][c] |
+ * a [B][C][ha][wa], b [B][C][hb][wb] bilinearly resized (align_corners=False) to ha x wa, max_norm = model.py:572-578
+ * (loss_cam_consistency model.py:368-390 with a = cam_diff, b = cams; loss_rcams_consistency :414-418 with a = rcams) */
+typedef struct {
+    const float* a;
+    const float* b;
+    const float* label;
+    float* partial;
+    int B, C, ha, wa, hb, wb, a_times_label;
+} dig_maxnorm_l1_args;
+int dig_maxnorm_l1(const dig_maxnorm_l1_args* a, void* stream);
+
+/* out[0] (+)= scale * sum(in[0..n))  (the .mean() over the partials above; the weighted total loss_trm, model.py:341-419) */
+typedef struct {
+    const float* in;
+    float* out;
+    float scale;
+    int accumulate, n;
+} dig_sum_scale_args;
+int dig_sum_scale(const dig_sum_scale_args* a, void* stream);
+
 /* One DDIM update of ddim_sample_from_t (ddp.py:792-814) for objective 'pred_v', elementwise over n fp32 values:
  *   x0  = clamp(sqrt_ac*x - sqrt_1mac*v, -1, 1)                      model_predictions, clip_x_start=True (ddp.py:662-666,630-634)
  *   eps = (sqrt_recip*x - x0) / sqrt_recipm1                         predict_noise_from_start (ddp.py:618-622)

@@ -453,6 +453,23 @@ def mctformer_lfca(sd, img, feat_diff, n_layers=12):
             "diff_pcls": top(F.relu(cam_diff)) - top(F.relu(-cam_diff))}
 
 
+def mctformer_outputs(sd, img, feat_diff=None, n_layers=12):
+    """The entries of MCTformerV2_DiG.forward's output dict that model_WSSS.update consumes (mctformer.py:293-346,
+    model.py:324-335): cls, pcls, cams (= relu(head)), mtatt, rcams and, with feat_diff, cam_diff / diff_cls / diff_pcls."""
+    col = {}
+    B = img.shape[0]
+    C = sd["cls_token"].shape[1]
+    if feat_diff is not None:
+        out = mctformer_lfca(sd, img, feat_diff, n_layers)
+        mctformer_cam(sd, img, n_layers, collect=col)
+    else:
+        out = {"rcams": mctformer_cam(sd, img, n_layers, collect=col)}
+    head = col["head"]
+    top = lambda t: torch.topk(t.reshape(B, C, -1), dim=-1, k=3)[0].mean(-1)
+    out.update(cls=col["tokens"][:, :C].mean(-1), pcls=top(F.relu(head)) - top(F.relu(-head)), cams=col["fmap"], mtatt=col["mtatt"])
+    return out
+
+
 def update_forward(sd_diffusion, sd_mct, img, noises, n_layers=12):
     """Forward part of model_WSSS.update, model.py:286-322 (guidance maps -> net_trm(img, feat_diff_list)) and
     model.py:396-404 (net_trm(img_diff)), composed from the restated pieces; eval mode.
@@ -460,6 +477,55 @@ def update_forward(sd_diffusion, sd_mct, img, noises, n_layers=12):
     maps, img_diff = guidance_maps(sd_diffusion, img, noises)
     outs = mctformer_lfca(sd_mct, img, maps, n_layers)
     return outs, mctformer_cam(sd_mct, img_diff, n_layers), maps, img_diff
+
+
+LOSS_NAMES = ("loss_cls", "loss_pred_diff", "loss_cam_consistency", "loss_cls_diff", "loss_rcams_consistency")
+
+
+def update_losses(outputs, outputs_diff, label, W=(1.0, 1.0, 1.0, 1.0, 10.0), T=5.0, A=0.2, epo=0, lfca_epoch=9):
+    """The loss terms of model_WSSS.update, models/model_ECCV24_DiG.py:337-421, with the reference's own torch calls
+    (F.multilabel_soft_margin_loss, nn.KLDivLoss(reduction='batchmean', log_target=True), max_norm model.py:572-578).
+    -> dict of python floats: the five loss_names and loss_trm."""
+    B, C = label.shape
+    kd_log = torch.nn.KLDivLoss(reduction="batchmean", log_target=True)  # model.py:203
+    msm = F.multilabel_soft_margin_loss
+    lab4 = label.view(B, C, 1, 1)
+    out = {}
+    out["loss_cls"] = W[0] * (msm(outputs["cls"], label) + msm(outputs["pcls"], label))
+    total = out["loss_cls"]
+    zero = torch.zeros(())
+    if W[1] > 0:
+        sp = F.softmax(outputs["diff_pcls"] / T, dim=1)
+        sc = F.softmax(outputs["diff_cls"] / T, dim=1)
+        tp = F.softmax(outputs["pcls"] / T, dim=1)
+        tc = F.softmax(outputs["cls"] / T, dim=1)
+        lg = lambda p: torch.log(torch.cat((p, 1 - p), dim=1))
+        out["loss_pred_diff"] = W[1] * (A * msm(outputs["diff_cls"], label) + A * msm(outputs["diff_pcls"], label)
+                                        + (1 - A) * (T * T) * kd_log(lg(sc), lg(tc)) * 0.5
+                                        + (1 - A) * (T * T) * kd_log(lg(sp), lg(tp)) * 0.5)
+        total = total + out["loss_pred_diff"]
+    else:
+        out["loss_pred_diff"] = zero
+    if W[2] > 0 and epo > lfca_epoch:
+        cd = outputs["cam_diff"]
+        _cams = max_norm(F.interpolate(outputs["cams"], size=cd.shape[2:], mode="bilinear", align_corners=False))
+        _cam_diff = max_norm(cd) * lab4
+        out["loss_cam_consistency"] = W[2] * ((_cam_diff - _cams) * lab4).abs().mean()
+        total = total + out["loss_cam_consistency"]
+    else:
+        out["loss_cam_consistency"] = zero
+    if W[3] > 0 or W[4] > 0:
+        out["loss_cls_diff"] = W[3] * (msm(outputs_diff["cls"], label) + msm(outputs_diff["pcls"], label))
+        total = total + out["loss_cls_diff"]
+    else:
+        out["loss_cls_diff"] = zero
+    if W[4] > 0 and epo > lfca_epoch:
+        out["loss_rcams_consistency"] = W[4] * ((max_norm(outputs["rcams"]) - max_norm(outputs_diff["rcams"])) * lab4).abs().mean()
+        total = total + out["loss_rcams_consistency"]
+    else:
+        out["loss_rcams_consistency"] = zero
+    out["loss_trm"] = total
+    return {k: float(v) for k, v in out.items()}
 
 
 def max_norm(cam):

@@ -12,6 +12,7 @@ Usage:  python oracle/gen_golden.py            (rewrites tests/golden/)
         python oracle/gen_golden.py lfca       (only the LFCA cases; merges into MANIFEST.json)
         python oracle/gen_golden.py keys       (only tests/golden/state_dict_keys.json)
         python oracle/gen_golden.py ddim       (only the ddim_sample_from_t cases)
+        python oracle/gen_golden.py losses     (only the update() forward-loss case)
 """
 import json
 import os
@@ -258,6 +259,38 @@ def case_ddim(ddp, name, dim, H, W, B, num_step, seed=4242):
     save(name, img=img, noise=noise, num_step=np.int64(num_step), times=np.array(pairs, np.int64), stack=stack)
 
 
+def case_losses(mct, name, C, H, W, B, hd, wd):
+    """(f)-4 first slice: the forward losses of model_WSSS.update (model.py:337-421).  The reference's two MCTformer passes
+    run here (eval mode) and their output dicts are the fixture's inputs; update() itself cannot be called (it needs the
+    training harness), so the expected losses are the oracle's restatement - the reference's own torch calls - on those
+    reference outputs, for the default weights and for epo on both sides of the LFCA gate."""
+    m = mct.deit_small_MCTformerV2_DiG(num_classes=C).eval()
+    synth.fill_state_dict(m, seed=0, skip_prefixes=("norm.",))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    img = synth.synth_imagenet_images(B, H, W, seed=5100)
+    img2 = synth.synth_imagenet_images(B, H, W, seed=5101)
+    label = synth.synth_labels(B, C, seed=11)
+    feat = [synth.normal("feat_diff", (B, 1024, hd, wd), seed=17 + j) * 1.5 for j in range(5)]
+    keys = ("cls", "pcls", "cams", "rcams", "cam_diff", "diff_cls", "diff_pcls")
+    with torch.no_grad():
+        outs = m(img, feat_diff=feat)
+        outs2 = m(img2)
+        o = O.mctformer_outputs(sd, img, feat)
+        o2 = O.mctformer_outputs(sd, img2)
+    d = {k: maxabs(outs[k], o[k]) for k in keys}
+    d.update({k + "_2": maxabs(outs2[k], o2[k]) for k in ("cls", "pcls", "rcams")})
+    arrays = {k: outs[k] for k in keys}
+    arrays.update({k + "_2": outs2[k] for k in ("cls", "pcls", "rcams")})
+    arrays["label"] = label
+    for epo in (0, 10):
+        lo = O.update_losses({k: outs[k] for k in keys}, {k: outs2[k] for k in ("cls", "pcls", "rcams")}, label, epo=epo)
+        lo_o = O.update_losses(o, o2, label, epo=epo)
+        d[f"loss_trm_epo{epo}"] = abs(lo["loss_trm"] - lo_o["loss_trm"])
+        arrays[f"losses_epo{epo}"] = np.array([lo[k] for k in O.LOSS_NAMES + ("loss_trm",)], np.float64)
+    record(name, **d)
+    save(name, **arrays)
+
+
 def synth_eval_set(C=20, seed=5):
     """Small synthetic CAM dicts + ground-truth maps (with 255 boundary pixels) for the evaluation cases."""
     rng = np.random.RandomState(seed)
@@ -357,6 +390,10 @@ def main():
         case_ddim(ddp, "ddim64_t60", 64, 64, 64, 1, 60)
         _merge_manifest()
         return
+    if sys.argv[1:] == ["losses"]:
+        case_losses(mct, "losses224_c20", 20, 224, 224, 2, 14, 14)
+        _merge_manifest()
+        return
     if sys.argv[1:] == ["eval"]:
         case_eval(ref_import.load_evaluation())
         _merge_manifest()
@@ -376,6 +413,7 @@ def main():
     case_eval(ref_import.load_evaluation())
     case_ddim(ddp, "ddim_tiny32_t100", 16, 32, 32, 2, 100)
     case_ddim(ddp, "ddim64_t60", 64, 64, 64, 1, 60)
+    case_losses(mct, "losses224_c20", 20, 224, 224, 2, 14, 14)
     case_state_dict_keys(ddp, mct)
     with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
         json.dump({"generator": "oracle/gen_golden.py", "torch": torch.__version__,

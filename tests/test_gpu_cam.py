@@ -176,6 +176,50 @@ def test_lfca_consumer_vs_reference_golden(golden, name, hd):
     assert float((o2["cam_diff"][1:] - outs["cam_diff"]).abs().max()) <= 1e-5
 
 
+def test_update_losses_vs_reference_golden(golden):
+    """SURVEY 8f-4, first slice: the forward losses of model_WSSS.update (model.py:337-421) on the kernels of csrc/losses.hip.
+    (1) The reference's own output dicts (fixture) go through dig_amd.losses.update_losses and every term must match the
+    reference's torch formulas on them to 1e-5 relative, for epo on both sides of the LFCA gate (epo > 9) and for other
+    weights / temperature; (2) the product's two MCTformer passes reproduce the dict entries the losses consume (cls, pcls,
+    cams added here; 2e-4) and the losses computed from them agree to 1e-3 relative."""
+    from dig_amd import losses
+    g = golden("losses224_c20")
+    label = T(g["label"]).to(DEV)
+    ref_o = {k: T(g[k]) for k in ("cls", "pcls", "cams", "rcams", "cam_diff", "diff_cls", "diff_pcls")}
+    ref_o2 = {k: T(g[k + "_2"]) for k in ("cls", "pcls", "rcams")}
+    dev = lambda d: {k: v.to(DEV) for k, v in d.items()}
+    names = losses.LOSS_NAMES + ("loss_trm",)
+    assert names == O.LOSS_NAMES + ("loss_trm",)
+    for epo in (0, 10):
+        got = losses.update_losses(dev(ref_o), dev(ref_o2), label, epo=epo)
+        ref = g[f"losses_epo{epo}"]
+        for i, n in enumerate(names):
+            assert got[n].shape == (1,) and abs(float(got[n]) - ref[i]) <= 1e-5 * max(1.0, abs(ref[i])), (epo, n, float(got[n]), ref[i])
+    for kw in (dict(W=(0.5, 2.0, 3.0, 0.0, 0.0), T=2.0, A=0.7, epo=12), dict(W=(1.0, 0.0, 0.0, 1.0, 4.0), T=10.0, A=0.1, epo=11)):
+        got = losses.update_losses(dev(ref_o), dev(ref_o2), label, **kw)
+        ref = O.update_losses(ref_o, ref_o2, label.cpu(), **kw)
+        for n in names:
+            assert abs(float(got[n]) - ref[n]) <= 1e-5 * max(1.0, abs(ref[n])), (kw, n, float(got[n]), ref[n])
+    # the product's own passes
+    m = create_model("deit_small_MCTformerV2_DiG", pretrained=False, num_classes=20, lfca=True)
+    synth.fill_state_dict(m, seed=0, skip_prefixes=("norm.",))
+    m = m.to(DEV).eval()
+    img = synth.synth_imagenet_images(2, 224, 224, seed=5100).to(DEV)
+    img2 = synth.synth_imagenet_images(2, 224, 224, seed=5101).to(DEV)
+    feat = [(synth.normal("feat_diff", (2, 1024, 14, 14), seed=17 + j) * 1.5).to(DEV) for j in range(5)]
+    outs, outs2 = m(img, feat_diff=feat), m(img2)
+    for k, r in list(ref_o.items()) + [(k + "_2", v) for k, v in ref_o2.items()]:
+        o = outs2[k[:-2]] if k.endswith("_2") else outs[k]
+        err = float((o.cpu() - r).abs().max())
+        assert o.shape == r.shape and err <= 2e-4 * max(1.0, float(r.abs().max())), (k, err)
+    got = losses.update_losses(outs, outs2, label, epo=10)
+    ref = g["losses_epo10"]
+    for i, n in enumerate(names):
+        assert abs(float(got[n]) - ref[i]) <= 1e-3 * max(1.0, abs(ref[i])), (n, float(got[n]), ref[i])
+    with pytest.raises(KeyError):
+        losses.update_losses(outs2, None, label, W=(1.0, 1.0, 0.0, 0.0, 0.0))
+
+
 def test_update_forward_pipeline_vs_oracle():
     """model.py:286-322,396-404 end to end (fp32): six Unet passes -> five guidance maps + img_diff -> MCTformer with the LFCA
     consumer -> MCTformer on the reconstruction, against the CPU oracle's composition of the same pieces."""

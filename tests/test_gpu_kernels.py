@@ -434,6 +434,62 @@ def test_vit_attn_rollout(cfg, monkeypatch):
     assert (acc_cls.cpu() - p.mean(1)[:, :ncls]).abs().max() <= 2e-6
 
 
+def test_head_and_loss_kernels():
+    """csrc/losses.hip against torch on random inputs: head_pool (relu + NCHW transpose, top-3 pooling with ties and P < 3),
+    row_mean (strided rows, two-input average), multilabel soft margin, the binary-split KL term, max_norm'd L1 with and
+    without the in-kernel bilinear resize, sum_scale with accumulation."""
+    g = lambda *s: rnd("hl" + "x".join(map(str, s)), s, 2.0)
+    for B, P, C in ((2, 196, 20), (1, 713, 20), (3, 2, 5), (2, 64, 80)):
+        x = g(B, P, C)
+        x[0, : min(P, 5), 0] = 1.25  # ties inside the top 3
+        relu = torch.empty(B, C, P, device=DEV)
+        pooled = torch.empty(B, C, device=DEV)
+        call("head_pool", **{"in": x.to(DEV)}, relu_nchw=relu, pooled=pooled, B=B, P=P, C=C)
+        v = x.permute(0, 2, 1)
+        k = min(3, P)
+        ref = v.clamp_min(0).topk(k, dim=-1)[0].mean(-1) - (-v).clamp_min(0).topk(k, dim=-1)[0].mean(-1)
+        assert torch.equal(relu.cpu(), v.clamp_min(0))
+        assert (pooled.cpu() - ref).abs().max() <= 1e-6 * max(1.0, float(ref.abs().max()))
+    B, C, D, N = 3, 20, 384, 216
+    x = g(B, N, D)
+    out = torch.empty(B, C, device=DEV)
+    call("row_mean", x0=x.to(DEV), x1=None, out=out, bstride0=N * D, bstride1=0, B=B, C=C, D=D)
+    assert (out.cpu() - x[:, :C].mean(-1)).abs().max() <= 1e-6
+    y = g(B, C, D)
+    call("row_mean", x0=x[:, :C].contiguous().to(DEV), x1=y.to(DEV), out=out, bstride0=C * D, bstride1=C * D, B=B, C=C, D=D)
+    assert (out.cpu() - ((x[:, :C] + y) / 2).mean(-1)).abs().max() <= 1e-6
+    for B, C in ((2, 20), (5, 80), (1, 3)):
+        lx, ly = g(B, C) * 3, (g(B, C, 1)[..., 0] > 0).float()
+        s, t = g(B, C, 2)[..., 0] * 4, g(B, C, 3)[..., 0] * 4
+        out = torch.full((1,), 7.0, device=DEV)
+        call("msm_loss", x=lx.to(DEV), y=ly.to(DEV), out=out, scale=1.5, accumulate=0, B=B, C=C)
+        ref = 1.5 * F.multilabel_soft_margin_loss(lx, ly)
+        assert abs(float(out) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
+        for Tt in (1.0, 5.0):
+            call("kd_bin_loss", student=s.to(DEV), teacher=t.to(DEV), out=out, T=Tt, scale=2.0, accumulate=1, B=B, C=C)
+            lg = lambda p: torch.log(torch.cat((p, 1 - p), dim=1))
+            ref = ref + 2.0 * torch.nn.KLDivLoss(reduction="batchmean", log_target=True)(lg(F.softmax(s / Tt, 1)), lg(F.softmax(t / Tt, 1)))
+        assert abs(float(out) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+
+    def max_norm(c):
+        c = F.relu(c)
+        mx, mn = c.flatten(2).max(-1)[0][..., None, None], c.flatten(2).min(-1)[0][..., None, None]
+        return F.relu(c - mn - 1e-5) / (mx - mn + 1e-5)
+
+    for (ha, wa), (hb, wb), atl in (((14, 14), (14, 14), 1), ((16, 16), (14, 14), 1), ((14, 14), (14, 14), 0), ((23, 31), (12, 40), 0)):
+        B, C = 2, 20
+        a, b = g(B, C, ha, wa), g(B, C, hb, wb)
+        lab = (g(B, C, 9)[..., 0] > 0).float()
+        partial = torch.empty(B * C, device=DEV)
+        call("maxnorm_l1", a=a.to(DEV), b=b.to(DEV), label=lab.to(DEV), partial=partial, B=B, C=C, ha=ha, wa=wa, hb=hb, wb=wb, a_times_label=atl)
+        out = torch.empty(1, device=DEV)
+        call("sum_scale", **{"in": partial}, out=out, scale=1.0 / (B * C * ha * wa), accumulate=0, n=B * C)
+        l4 = lab.view(B, C, 1, 1)
+        an = max_norm(a) * (l4 if atl else 1.0)
+        ref = ((an - max_norm(F.interpolate(b, size=(ha, wa), mode="bilinear", align_corners=False))) * l4).abs().mean()
+        assert abs(float(out) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref))), ((ha, wa), (hb, wb), float(out), float(ref))
+
+
 def test_conv3x3_random_shapes():
     """Seeded sweep over ragged shapes and channel combinations (every conv3x3 dispatch class: weight-stationary, double-buffered,
     generic bf16/fp32; concat / nearest-x2 / prologue), bf16 and fp32, against F.conv2d."""
