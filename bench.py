@@ -150,6 +150,46 @@ def main():
     sync_all()
     elapsed_instr = time.perf_counter() - t1
     state["on"] = False
+    # third pass (N = 1 only, a few steps): a HIP event pair around EVERY C-ABI launch, so that the per-class table covers the
+    # whole step and can be summed against ms_per_step (what is left over is launch gaps + the torch allocator / copies)
+    all_log, step_classes = [], None
+    if world == 1 and not multi:
+        from dig_amd import _lib as L_
+        pend = []
+
+        def trace(fn, kw, phase):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            if phase == 0:
+                pend.append(ev)
+                return
+            name = fn
+            if fn == "conv3x3":
+                if kw["Cout"] == 64 and kw["C0"] == 64 and kw["C1"] == 0:
+                    name = "conv3x3 64->64 (ws64)"
+                elif kw["Cout"] % 128 == 0:
+                    name = "conv3x3 Cout>=128 (db)"
+                else:
+                    name = "conv3x3 128->64 (rs128)" if kw["C0"] + kw["C1"] == 128 else "conv3x3 other"
+            elif fn in ("la_kvctx", "la_merge", "la_out"):
+                name = "linear attention (kvctx+merge+out)"
+            elif fn in ("gemm_nt", "pw_res"):
+                name = fn + (" @256^2" if kw.get("M", kw.get("rows", 0)) >= B * S * S else "")
+            all_log.append((name, pend.pop(), ev))
+
+        n3 = min(args.steps, 5)
+        L_.TRACE = trace
+        for _ in range(n3):
+            step()
+        torch.cuda.synchronize()
+        L_.TRACE = None
+        agg = {}
+        for name, e0, e1 in all_log:
+            d = agg.setdefault(name, [0.0, 0])
+            d[0] += e0.elapsed_time(e1)
+            d[1] += 1
+        step_classes = {k: {"ms_per_step": round(v[0] / n3, 3), "launches_per_step": round(v[1] / n3, 1)}
+                        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
     if multi:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -188,6 +228,11 @@ def main():
                 "flops_per_launch_avg": fl / n,
                 "classes": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(1e3 * v[1] / args.steps, 3),
                                 "launches_per_step": v[2] // args.steps, "hbm_algorithmic_GBps": round(v[3] / v[1] / 1e9, 1)} for k, v in per_cls.items()}}
+    if roof and step_classes:
+        ssum = sum(v["ms_per_step"] for v in step_classes.values())
+        roof["step_classes"] = {"what": "HIP-event time of every C-ABI launch of one step, by kernel class (third pass, events around each launch)",
+                                "classes": step_classes, "sum_ms_per_step": round(ssum, 3),
+                                "unattributed_ms_per_step": round(ms_per_step - ssum, 3)}
     gflop = GFLOP_PER_MAP.get(S)
     whole = {"tflops": round(maps_per_s / world * gflop / 1e3, 2), "frac_of_mfma_peak": round(maps_per_s / world * gflop / 1e3 / peak, 4)} if gflop else None
 

@@ -81,6 +81,9 @@ def _ptr(x):
     return x.data_ptr()  # torch.Tensor
 
 
+TRACE = None  # bench.py's per-launch HIP-event hook: callable(fn, kw, phase) with phase 0 before / 1 after the launch
+
+
 def call(fn, stream=None, **kw):
     """Call `int dig_<fn>(const dig_<fn>_args*, void* stream)` with keyword fields; tensors become pointers.
     The launch goes to the device the tensor arguments live on (they must all share one HIP device; CPU tensors and
@@ -114,6 +117,9 @@ def call(fn, stream=None, **kw):
             setattr(args, k, ftype(*v))
         else:
             setattr(args, k, v)
+    tr = TRACE
+    if tr is not None:
+        tr(fn, kw, 0)
     if dev is None or dev.index in (None, torch.cuda.current_device()):
         if stream is None:
             stream = torch.cuda.current_stream().cuda_stream
@@ -125,6 +131,8 @@ def call(fn, stream=None, **kw):
             rc = getattr(L, "dig_" + fn)(ctypes.byref(args), ctypes.c_void_p(stream))
     if rc != 0:
         raise RuntimeError(f"dig_{fn} failed ({rc}): {L.dig_last_error().decode()}")
+    if tr is not None:
+        tr(fn, kw, 1)
 
 
 def dtype_code(torch_dtype):

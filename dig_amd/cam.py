@@ -146,20 +146,20 @@ def lfca_forward(L, qkv, C, feat, heads=8):
     q = _layernorm(q, L["norm_k"])
     k = _layernorm(ops.linear_rows(kv, L["key"][0], bias=L["key"][1], out_f32=True), L["norm_k"])    # [B,hd,wd,D] fp32
     v = _layernorm(_cast(ops.conv3x3(kv, L["value"], want_stats=False)[0], F32), L["norm_v"])        # [B,hd,wd,Df] fp32
-    # 8-head cross attention (mctformer.py:138-151).  The key count (196 at 224x224) need not be a multiple of the GEMM's
-    # 8-element K vectors: the logits live in rows of Nfp >= Nf columns whose tail is -inf (softmax -> exactly 0 there), and
-    # v^T gets 8 floats of zero slack so the last row's vector tail stays inside the buffer.
+    # 8-head cross attention (mctformer.py:138-151).  The key count (196 at 224x224, 225 for 15x15 maps) need not be a
+    # multiple of the GEMM's 8-element K vectors: the logits live in rows of Nfp >= Nf columns whose tail is -inf (softmax ->
+    # exactly 0 there) and v^T in rows of the same pitch whose tail is zero, so the padded K range multiplies 0 by 0.
     Nfp = (Nf + 7) // 8 * 8
     dq, dv = D // heads, Df // heads
     S = torch.full((B, heads, Nq, Nfp), float("-inf"), dtype=F32, device=dev)
     ops.gemm_nt(q, k, S, Nq, Nf, dq, dtype=F32, lda0=D, ldb=D, ldc=Nfp, alpha=1.0 / ((384 // 8) ** 0.5), batch=B * heads, z_inner=heads,
                 sa=(Nq * D, dq), sb=(Nf * D, dq), sc=(heads * Nq * Nfp, Nq * Nfp))
     Pm = ops.row_softmax(S, F32)
-    vT = torch.zeros(B * Df * Nf + 8, dtype=F32, device=dev)
-    call("nhwc_to_nchw_f32", **{"in": v}, out=vT, B=B, C=Df, HW=Nf, dtype=1)
+    vT = torch.zeros(B, Df, Nfp, dtype=F32, device=dev)
+    call("nhwc_to_nchw_f32", **{"in": v}, out=vT, B=B, C=Df, HW=Nf, dtype=1, out_ld=Nfp)
     o = torch.empty(B, Nq, Df, dtype=F32, device=dev)
-    ops.gemm_nt(Pm, vT, o, Nq, dv, Nfp, dtype=F32, lda0=Nfp, ldb=Nf, ldc=Df, batch=B * heads, z_inner=heads,
-                sa=(heads * Nq * Nfp, Nq * Nfp), sb=(Df * Nf, dv * Nf), sc=(Nq * Df, dv))
+    ops.gemm_nt(Pm, vT, o, Nq, dv, Nfp, dtype=F32, lda0=Nfp, ldb=Nfp, ldc=Df, batch=B * heads, z_inner=heads,
+                sa=(heads * Nq * Nfp, Nq * Nfp), sb=(Df * Nfp, dv * Nfp), sc=(Nq * Df, dv))
     # class-token branch (mctformer.py:153-158): rows [:C] of every image
     x_c = torch.empty(B, C, D, dtype=F32, device=dev)
     ops.gemm_nt(o, L["mlp_c0"][0], x_c, C, D, Df, dtype=F32, bias=L["mlp_c0"][1], res=qkv, ldr=D3, batch=B,

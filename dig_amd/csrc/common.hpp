@@ -3,6 +3,8 @@
 // accumulation, statistics and softmax are always fp32.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdint.h>
 
 #include "../../include/dig_hip.h"

@@ -342,15 +342,15 @@ int launch(const dig_conv3x3_args* a, hipStream_t stream) {
     p.tiles_x = cdiv(a->W, TILE_W);
     p.tiles_y = cdiv(a->H, 4 * WPG);
     constexpr size_t lds = conv_lds_bytes<T, BN, KC, WPG>();
-    static bool attr_set[64] = {};  // per instantiation, per device
+    static std::atomic<bool> attr_set[64];  // per instantiation, per device
     int dev = 0;
     (void)hipGetDevice(&dev);
     dev &= 63;
-    if (!attr_set[dev]) {
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel<T, BN, KC, PF, WPG, WNG>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "conv3x3: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     dim3 grid(a->B * p.tiles_x * p.tiles_y, cdiv(a->Cout, BN));
     hipLaunchKernelGGL((conv3x3_kernel<T, BN, KC, PF, WPG, WNG>), grid, dim3(64 * WPG * WNG), lds, stream, p);

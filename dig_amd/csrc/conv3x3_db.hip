@@ -302,14 +302,14 @@ int conv3x3_db_launch(const dig_conv3x3_args* a, hipStream_t stream) {
     p.B = a->B; p.H = a->H; p.W = a->W; p.Cout = a->Cout; p.groups = a->groups; p.up2 = a->up2;
     p.tiles_x = cdiv(a->W, 16);
     p.tiles_y = cdiv(a->H, TILE_H);
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
     dev &= 63;
-    if (!attr_set[dev]) {
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)conv3x3_db_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS);
         DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "conv3x3(db): cannot raise dynamic LDS to %d: %s", DB_LDS, hipGetErrorString(e));
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     dim3 grid(a->B * p.tiles_x * p.tiles_y, a->Cout / BN);
     hipLaunchKernelGGL(conv3x3_db_kernel, grid, dim3(NTHREADS), DB_LDS, stream, p);

@@ -532,19 +532,21 @@ int conv3x3_rs128_launch(const dig_conv3x3_args* a, hipStream_t stream) {
     p.ntiles = a->B * p.tiles_x * p.tiles_y;
     // 32-bit byte offsets inside one image of a source
     DIG_CHECK(src_px * a->C0 * 2 < (1ll << 31), DIG_EINVAL, "conv3x3(rs128): source image too large for 32-bit offsets");
-    static int ncu[64] = {};
+    static std::atomic<int> ncu[64];  // zero-initialised; racing first calls both query and store the same value
     int device = 0;
     (void)hipGetDevice(&device);
     const int dev = device & 63;
-    if (!ncu[dev]) {
+    int ncus = ncu[dev].load(std::memory_order_acquire);
+    if (!ncus) {
         hipError_t e = hipFuncSetAttribute((const void*)conv3x3_rs128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
         DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "conv3x3(rs128): cannot raise dynamic LDS to %d: %s", RS_LDS, hipGetErrorString(e));
         int n = 0;
         e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device);
         DIG_CHECK(e == hipSuccess && n > 0, DIG_ELAUNCH, "conv3x3(rs128): cannot query the CU count");
-        ncu[dev] = n;
+        ncu[dev].store(n, std::memory_order_release);
+        ncus = n;
     }
-    int grid = p.ntiles < ncu[dev] ? p.ntiles : ncu[dev];
+    int grid = p.ntiles < ncus ? p.ntiles : ncus;
     if (const char* g = getenv("DIG_RS_GRID")) {  // test hook: a small grid makes every block walk many tiles
         const int v = atoi(g);
         if (v > 0 && v < grid) grid = v;

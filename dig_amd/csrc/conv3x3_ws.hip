@@ -78,7 +78,23 @@ struct WsParams {
     float* stats;
     long long bstride;
     int B, H, W, up2, tiles_x, tiles_y, ntiles;
+#ifdef WS_ASSERT_ADDR
+    long long in_elems, out_elems, stats_elems;  // extents of the three global buffers, for the debug build's address checks
+#endif
 };
+
+#ifdef WS_ASSERT_ADDR
+// Debug build (-DWS_ASSERT_ADDR): every global address the kernel forms is checked against the extent of
+// its buffer before the access; a violation is counted (first offender recorded) and the access is redirected to element 0
+// instead of being performed.  [0] = count, [1] = kind (1 halo load, 2 output store, 3 stats store), [2] = offending element
+// offset, [3] = tile index.  Read back with dig_debug_ws_addr_violations().
+__device__ long long ws_addr_viol[4];
+#define WS_CHECK(kind, off_, lim_, tile_)                                                \
+    (((long long)(off_) < 0 || (long long)(off_) > (long long)(lim_)) ?                    \
+         (atomicAdd((unsigned long long*)&ws_addr_viol[0], 1ull) == 0                       \
+              ? (ws_addr_viol[1] = (kind), ws_addr_viol[2] = (long long)(off_), ws_addr_viol[3] = (tile_), 0ll) : 0ll) \
+         : (long long)(off_))
+#endif
 
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_ws64_kernel(WsParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -311,7 +327,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         bf16* outw = p.out + (((size_t)b * p.H + ty0 + wg * 4) * p.W + tx0) * 64;  // scalar
         const unsigned lo = (unsigned)(lq * 64 + sv * 8);
 #pragma unroll
+#ifdef WS_ASSERT_ADDR
+        for (int i = i0; i < i1; i++)
+            *reinterpret_cast<bf16x8*>(p.out + WS_CHECK(2, (outw - p.out) + (long long)(((i >> 1) * p.W + (i & 1) * 8) * 64) + lo, p.out_elems - 8, t)) = od[i];
+#else
         for (int i = i0; i < i1; i++) *reinterpret_cast<bf16x8*>(outw + (size_t)(((i >> 1) * p.W + (i & 1) * 8) * 64) + lo) = od[i];
+#endif
     };
     auto epilogue_stats = [&](int t, const float (&st)[16]) {
         int b, tl;
@@ -356,7 +377,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if ((lane & 3) == 0) {
                 const int j = lane >> 2;  // = 8*kind + 4*nr + q4
                 const int kind = j >> 3, g = j & 7;
+#ifdef WS_ASSERT_ADDR
+                p.stats[WS_CHECK(3, (((long long)b * 8 + g) * (tiles_img * 4) + tl * 4 + wg) * 2 + kind, p.stats_elems - 1, t)] = a1;
+#else
                 p.stats[(((size_t)b * 8 + g) * (tiles_img * 4) + tl * 4 + wg) * 2 + kind] = a1;
+#endif
             }
         }
         }
@@ -401,7 +426,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 gaddr(tn, off, base, hok, interior);
                 __builtin_amdgcn_sched_barrier(0);
 #ifndef WS_NO_GLOAD
+#ifdef WS_ASSERT_ADDR
+#define WS_LOADS(a, b) _Pragma("unroll") for (int i = a; i < b; i++) pre[i] = *reinterpret_cast<const bf16x8*>(p.in + WS_CHECK(1, (base - p.in) + (long long)off[i], p.in_elems - 8, tn));
+#else
 #define WS_LOADS(a, b) _Pragma("unroll") for (int i = a; i < b; i++) pre[i] = *reinterpret_cast<const bf16x8*>(base + off[i]);
+#endif
 #else
 #define WS_LOADS(a, b) _Pragma("unroll") for (int i = a; i < b; i++) pre[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -519,28 +548,42 @@ int conv3x3_ws64_launch(const dig_conv3x3_args* a, hipStream_t stream) {
     p.tiles_x = a->W / 16;
     p.tiles_y = a->H / 16;
     p.ntiles = a->B * p.tiles_x * p.tiles_y;
-    static int ncu[64] = {};
+    static std::atomic<int> ncu[64];  // zero-initialised; racing first calls both query and store the same value
     int device = 0;
     (void)hipGetDevice(&device);
     const int dev = device & 63;
-    if (!ncu[dev]) {
+    int ncus = ncu[dev].load(std::memory_order_acquire);
+    if (!ncus) {
         hipError_t e = hipFuncSetAttribute((const void*)conv3x3_ws64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS);
         DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "conv3x3(ws64): cannot raise dynamic LDS to %d: %s", WS_LDS, hipGetErrorString(e));
         int n = 0;
         e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device);
         DIG_CHECK(e == hipSuccess && n > 0, DIG_ELAUNCH, "conv3x3(ws64): cannot query the CU count");
-        ncu[dev] = n;
+        ncu[dev].store(n, std::memory_order_release);
+        ncus = n;
     }
     int grid = (p.ntiles + 1) / 2;
-    if (grid > ncu[dev]) grid = ncu[dev];
+    if (grid > ncus) grid = ncus;
     if (const char* g = getenv("DIG_WS_GRID")) {  // test hook: a small grid makes every block walk many tiles
         const int v = atoi(g);
         if (v > 0 && v < grid) grid = v;
     }
+#ifdef WS_ASSERT_ADDR
+    const long long src_px = (long long)(a->up2 ? (a->H / 2) * (a->W / 2) : a->H * a->W);
+    p.in_elems = p.bstride * (a->B - 1) + src_px * 64;
+    p.out_elems = (long long)a->B * a->H * a->W * 64;
+    p.stats_elems = (long long)a->B * 8 * p.tiles_x * p.tiles_y * 4 * 2;
+#endif
     hipLaunchKernelGGL(conv3x3_ws64_kernel, dim3(grid), dim3(512), WS_LDS, stream, p);
     DIG_LAUNCH_CHECK("conv3x3(ws64)");
     return DIG_OK;
 }
+
+#ifdef WS_ASSERT_ADDR
+extern "C" int dig_debug_ws_addr_violations(long long* host4) {
+    return (int)hipMemcpyFromSymbol(host4, HIP_SYMBOL(ws_addr_viol), sizeof(long long) * 4);
+}
+#endif
 
 #ifdef WS_TRACE
 extern "C" int dig_debug_ws_trace(unsigned long long* host) {

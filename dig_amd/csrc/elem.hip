@@ -289,14 +289,14 @@ template <typename T> __global__ void nchw_to_nhwc_kernel(const float* in, T* ou
         out[i] = from_f32<T>(in[((size_t)b * C + c) * HW + pix]);
     }
 }
-template <typename T> __global__ void nhwc_to_nchw_kernel(const T* in, float* out, int B, int C, int HW) {
+template <typename T> __global__ void nhwc_to_nchw_kernel(const T* in, float* out, int B, int C, int HW, int ld) {
     const size_t total = (size_t)B * C * HW;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int pix = (int)(i % HW);
         const size_t rest = i / HW;
         const int c = (int)(rest % C);
         const int b = (int)(rest / C);
-        out[i] = to_f32<T>(in[((size_t)b * HW + pix) * C + c]);
+        out[rest * ld + pix] = to_f32<T>(in[((size_t)b * HW + pix) * C + c]);
     }
 }
 
@@ -454,9 +454,10 @@ extern "C" int dig_nchw_f32_to_nhwc(const dig_layout_args* a, void* stream_) {
 extern "C" int dig_nhwc_to_nchw_f32(const dig_layout_args* a, void* stream_) {
     STREAM;
     DIG_CHECK(a && a->in && a->out, DIG_EINVAL, "layout: null pointer");
-    const int g = grid_for((size_t)a->B * a->C * a->HW, 256);
-    if (a->dtype == DIG_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16>, dim3(g), dim3(256), 0, stream, (const bf16*)a->in, (float*)a->out, a->B, a->C, a->HW);
-    else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)a->in, (float*)a->out, a->B, a->C, a->HW);
+    DIG_CHECK(a->out_ld == 0 || a->out_ld >= a->HW, DIG_EINVAL, "layout: out_ld=%d < HW=%d", a->out_ld, a->HW);
+    const int g = grid_for((size_t)a->B * a->C * a->HW, 256), ld = a->out_ld ? a->out_ld : a->HW;
+    if (a->dtype == DIG_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16>, dim3(g), dim3(256), 0, stream, (const bf16*)a->in, (float*)a->out, a->B, a->C, a->HW, ld);
+    else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)a->in, (float*)a->out, a->B, a->C, a->HW, ld);
     DIG_LAUNCH_CHECK("nhwc_to_nchw");
     return DIG_OK;
 }

@@ -534,14 +534,14 @@ template <typename T, int BN, int BK> int launch(const dig_gemm_args* a, hipStre
         static const bool force_old = getenv("DIG_GEMM_NO_DMA") != nullptr;  // test hook: keep the register-staged kernel
         if (a->K % 32 == 0 && !force_old) {
             constexpr size_t lds = dma_lds<BN>();
-            static bool attr_set[64] = {};
+            static std::atomic<bool> attr_set[64];
             int dev = 0;
             (void)hipGetDevice(&dev);
             dev &= 63;
-            if (!attr_set[dev]) {
+            if (!attr_set[dev].load(std::memory_order_acquire)) {
                 hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "gemm_nt: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
-                attr_set[dev] = true;
+                attr_set[dev].store(true, std::memory_order_release);
             }
             const int mtiles = cdiv(a->M, BM), ntiles = cdiv(a->N, BN);
             dim3 grid((mtiles >= 16 ? cdiv(mtiles, 8) * 8 : mtiles) * ntiles, 1, a->batch > 0 ? a->batch : 1);

@@ -140,14 +140,14 @@ template <int KS, int NT> size_t pw_lds() {
 
 template <int KS, int NT> int launch(const dig_pw_res_args* a, hipStream_t st) {
     const size_t lds = pw_lds<KS, NT>();
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
     dev &= 63;
-    if (!attr_set[dev]) {
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)pw_res_kernel<KS, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "pw_res: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     const long long nsub = a->M / 32;
     const long long groups = (nsub + 3) / 4;  // 4 sub-tiles (one per wave) per block-iteration

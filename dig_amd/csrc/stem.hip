@@ -292,14 +292,14 @@ extern "C" int dig_qsample_stem(const dig_stem_args* a, void* stream_) {
     DIG_CHECK(a && a->img && a->noise && a->t && a->sqrt_ac && a->sqrt_1mac && a->w && a->bias && a->out, DIG_EINVAL, "qsample_stem: null pointer");
     DIG_CHECK(a->B > 0 && a->H > 0 && a->W > 0 && a->Cout > 0 && a->Cout % 8 == 0, DIG_EINVAL, "qsample_stem: bad shape (Cout=%d)", a->Cout);
     if (a->dtype == DIG_BF16 && a->Cout == 64 && ((uintptr_t)a->bias % 16) == 0) {
-        static bool attr_set[64] = {};
+        static std::atomic<bool> attr_set[64];
         int dev = 0;
         (void)hipGetDevice(&dev);
         dev &= 63;
-        if (!attr_set[dev]) {
+        if (!attr_set[dev].load(std::memory_order_acquire)) {
             hipError_t e = hipFuncSetAttribute((const void*)stem64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
             DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "qsample_stem: cannot raise dynamic LDS: %s", hipGetErrorString(e));
-            attr_set[dev] = true;
+            attr_set[dev].store(true, std::memory_order_release);
         }
         const int tx = cdiv(a->W, S_TW), ty = cdiv(a->H, S_TH);
         const int total = a->B * tx * ty;

@@ -410,11 +410,12 @@ typedef struct {
 } dig_bilinear_ac_args;
 int dig_bilinear_ac_concat(const dig_bilinear_ac_args* a, void* stream);
 
-/* layout converters (test / boundary glue): NCHW fp32 <-> NHWC dtype */
+/* layout converters (test / boundary glue): NCHW fp32 <-> NHWC dtype.  out_ld (nhwc_to_nchw only; 0 = HW): pitch in floats
+ * of the output's [B][C] rows, >= HW - the columns HW..out_ld-1 are left untouched (LFCA pads v^T rows to the GEMM's K vector) */
 typedef struct {
     const void* in;
     void* out;
-    int B, C, HW, dtype;
+    int B, C, HW, dtype, out_ld;
 } dig_layout_args;
 int dig_nchw_f32_to_nhwc(const dig_layout_args* a, void* stream);
 int dig_nhwc_to_nchw_f32(const dig_layout_args* a, void* stream);

@@ -176,6 +176,24 @@ def test_lfca_consumer_vs_reference_golden(golden, name, hd):
     assert float((o2["cam_diff"][1:] - outs["cam_diff"]).abs().max()) <= 1e-5
 
 
+def test_lfca_odd_map_size_vs_oracle():
+    """Guidance maps of a 240x240 diffusion input are 15x15: 225 keys, not a multiple of the GEMM's vector width (the padded
+    logits / v^T rows of cam.lfca_forward, pad columns -inf / 0).  Against the CPU oracle, which is pinned on the 14x14 and
+    16x16 fixtures above."""
+    m = create_model("deit_small_MCTformerV2_DiG", pretrained=False, num_classes=20, lfca=True)
+    synth.fill_state_dict(m, seed=0, skip_prefixes=("norm.",))
+    m.eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    img = synth.synth_imagenet_images(1, 224, 224, seed=4401)
+    feat = [synth.normal("feat_diff15", (1, 1024, 15, 15), seed=70 + j) * 1.5 for j in range(5)]
+    ref = O.mctformer_lfca(sd, img, feat)
+    outs = m.to(DEV)(img.to(DEV), feat_diff=[f.to(DEV) for f in feat])
+    assert outs["cam_diff"].shape == (1, 20, 15, 15)
+    for k in ("rcams", "cam_diff", "diff_cls", "diff_pcls"):
+        err = float((outs[k].cpu() - ref[k]).abs().max())
+        assert torch.isfinite(outs[k]).all() and err <= 2e-4 * max(1.0, float(ref[k].abs().max())), (k, err)
+
+
 def test_update_losses_vs_reference_golden(golden):
     """SURVEY 8f-4, first slice: the forward losses of model_WSSS.update (model.py:337-421) on the kernels of csrc/losses.hip.
     (1) The reference's own output dicts (fixture) go through dig_amd.losses.update_losses and every term must match the
