@@ -371,7 +371,7 @@ void conv_config(int Cout, int dtype, int* BN, int* KC, int* TH) {
 
 extern "C" int dig_conv3x3_tiles(int H, int W, int C0, int C1, int Cout, int groups, int dtype) {
     if (conv3x3_ws64_eligible(H, W, C0, C1, Cout, groups, dtype)) return (H / 16) * (W / 16) * 4;  // per-wave partials
-    if (conv3x3_db_eligible(C0, C1, Cout, dtype)) return cdiv(H, 32) * cdiv(W, TILE_W);                // 32x16-pixel tiles
+    if (conv3x3_db_eligible(C0, C1, Cout, dtype)) return cdiv(H, 16) * cdiv(W, TILE_W);  // one partial per 16x16 pixels from either tile height
     int BN, KC, TH;
     conv_config(Cout, dtype, &BN, &KC, &TH);
     return cdiv(H, TH) * cdiv(W, TILE_W);

@@ -12,6 +12,8 @@
 // The weight slabs are packed on the host exactly as they sit in LDS: [n_tile][chunk][9][128][16] with the two 16-byte
 // halves of a row swapped when bit 3 of the row index is set - with that, unpadded 32-byte rows are read
 // conflict-free by ds_read_b128 (dig_conv3x3_wlayout reports the layout to the packer).
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -19,14 +21,19 @@ namespace {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
-constexpr int BN = 128, KC = 16, KCP = KC + 8, TILE_H = 32, HALO_W = 18, HALO_H = TILE_H + 2;
+// NW = waves per block = 4-row pixel groups per tile: 8 (32x16-pixel tile, the default) or 4 (16x16-pixel tile, for launches
+// whose 32-row tiles would leave CUs idle: e.g. 256->256 at 32x32 with B = 32 is 128 blocks of 8 waves or 256 of 4)
+constexpr int BN = 128, KC = 16, KCP = KC + 8, HALO_W = 18;
 constexpr int HROW = 512;                               // halo row stride in elements (18 * 24 * 2 B = 864 -> 1024 B)
-constexpr int HALO_BYTES = HALO_H * HROW * 2;           // 34816
 constexpr int WSLAB_BYTES = 9 * BN * KC * 2;            // 36864
-constexpr int BUF_BYTES = HALO_BYTES + WSLAB_BYTES;     // 71680
-constexpr int DB_LDS = 2 * BUF_BYTES;                   // 143360
-constexpr int NTHREADS = 512, NH = 3;                   // halo vectors per thread per chunk (34*18*2 = 1224 of 1536 slots used)
+constexpr int NH = 3;                                   // halo vectors per thread per chunk (NW=8: 34*18*2 = 1224 of 1536 slots; NW=4: 648 of 768)
 constexpr int OS = BN + 4;                              // fp32 staging row stride of the epilogue
+template <int NW> struct DbCfg {
+    static constexpr int TILE_H = 4 * NW, HALO_H = TILE_H + 2, NTHREADS = 64 * NW;
+    static constexpr int HALO_BYTES = HALO_H * HROW * 2;           // NW=8: 34816
+    static constexpr int BUF_BYTES = HALO_BYTES + WSLAB_BYTES;     // NW=8: 71680
+    static constexpr int DB_LDS = 2 * BUF_BYTES;                   // NW=8: 143360, NW=4: 110592 (the epilogue staging needs NW*32*OS*4 <= that)
+};
 
 #ifndef DB_TAP_ISSUE
 #define DB_TAP_ISSUE 0
@@ -57,7 +64,9 @@ struct DbParams {
     int B, H, W, Cout, groups, up2, tiles_x, tiles_y;
 };
 
-__global__ __launch_bounds__(NTHREADS, 2) void conv3x3_db_kernel(DbParams p) {
+template <int NW> __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(DbParams p) {
+    constexpr int TILE_H = DbCfg<NW>::TILE_H, HALO_H = DbCfg<NW>::HALO_H, NTHREADS = DbCfg<NW>::NTHREADS;
+    constexpr int HALO_BYTES = DbCfg<NW>::HALO_BYTES, BUF_BYTES = DbCfg<NW>::BUF_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_db_kernel(DbParams p) {
     auto wload = [&](int ci, unsigned char* buf) {
         const unsigned char* slab = wbase + (size_t)ci * WSLAB_BYTES;
         unsigned char* wl = buf + HALO_BYTES;
-        for (int q = wave; q < WSLAB_BYTES / 1024; q += 8)
+        for (int q = wave; q < WSLAB_BYTES / 1024; q += NW)
             __builtin_amdgcn_global_load_lds((glb_void*)(slab + q * 1024 + lane * 16), (lds_void*)(wl + q * 1024), 16, 0, 0);
     };
 
@@ -189,14 +198,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_db_kernel(DbParams p) {
             }
             // the halo registers go to LDS inside the MFMA sequence (the partner wave of the SIMD keeps the pipe busy
             // meanwhile); the two wave halves do it at different taps so that they do not all leave the pipe at once
-            if (tap == (wave < 4 ? DB_TAP_STORE_A : DB_TAP_STORE_B) && more) lstore(ci + 1, nxt);
+            if (tap == (wave < NW / 2 ? DB_TAP_STORE_A : DB_TAP_STORE_B) && more) lstore(ci + 1, nxt);
         }
         DB_STAMP(2)
         DB_STAMP(3)
         __syncthreads();
         DB_STAMP(4)
 #ifdef DB_TRACE
-        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && ci < 64)
+        if (NW == 8 && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && ci < 64)
             for (int s_ = 0; s_ < 5; s_++) db_trace[(wave * 64 + ci) * 8 + s_] = db_t[s_];
 #endif
     }
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_db_kernel(DbParams p) {
             }
         }
         __syncthreads();
-        for (int idx = tid; idx < 256 * (BN / 8); idx += NTHREADS) {
+        for (int idx = tid; idx < NW * 32 * (BN / 8); idx += NTHREADS) {
             const int pl = idx / (BN / 8), v8 = idx - pl * (BN / 8);
             const int wv = pl >> 5, row = pl & 31;
             const int Y = ty0 + wv * 4 + mr * 2 + (row >> 4), X = tx0 + (row & 15);
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_db_kernel(DbParams p) {
     }
     if (p.stats != nullptr) {
         float* st = reinterpret_cast<float*>(smem);  // [pixel group][half][BN][2], then [BN][2]
-        float* col = st + 8 * 2 * BN * 2;
+        float* col = st + NW * 2 * BN * 2;
 #pragma unroll
         for (int nr = 0; nr < 4; nr++) {
             float* d = st + (((pg * 2 + hf) * BN) + nr * 32 + r) * 2;
@@ -251,28 +260,36 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_db_kernel(DbParams p) {
             d[1] = css[nr];
         }
         __syncthreads();
+        // One partial per 16-row sub-tile (NS per block), each summed in the order the 16-row kernel uses for that sub-tile:
+        // the two tile heights write bit-identical statistics, so the launch heuristic cannot break batch invariance.
+        constexpr int NS = NW / 4;
         if (tid < BN) {
-            float s = 0.f, ss = 0.f;
 #pragma unroll
-            for (int k = 0; k < 16; k++) {  // fixed order -> deterministic
-                s += st[(k * BN + tid) * 2];
-                ss += st[(k * BN + tid) * 2 + 1];
+            for (int ns = 0; ns < NS; ns++) {
+                float s = 0.f, ss = 0.f;
+#pragma unroll
+                for (int k = ns * 8; k < ns * 8 + 8; k++) {  // fixed order -> deterministic
+                    s += st[(k * BN + tid) * 2];
+                    ss += st[(k * BN + tid) * 2 + 1];
+                }
+                col[(ns * BN + tid) * 2] = s;
+                col[(ns * BN + tid) * 2 + 1] = ss;
             }
-            col[tid * 2] = s;
-            col[tid * 2 + 1] = ss;
         }
         __syncthreads();
         const int cpg = p.Cout / p.groups;
         const int gpt = BN / cpg;  // groups covered by this N tile (host guarantees cpg | BN)
-        if (tid < gpt) {
-            const int g = (n0 / cpg) + tid;
-            if (g < p.groups) {
+        if (tid < gpt * NS) {
+            const int ns = tid / gpt, gi = tid - ns * gpt;
+            const int g = (n0 / cpg) + gi;
+            const int ty16 = (tile / p.tiles_x) * NS + ns, rows16 = (p.H + 15) / 16;
+            if (g < p.groups && ty16 < rows16) {
                 float s = 0.f, ss = 0.f;
                 for (int c = 0; c < cpg; c++) {
-                    s += col[(tid * cpg + c) * 2];
-                    ss += col[(tid * cpg + c) * 2 + 1];
+                    s += col[(ns * BN + gi * cpg + c) * 2];
+                    ss += col[(ns * BN + gi * cpg + c) * 2 + 1];
                 }
-                float* dst = p.stats + (((size_t)b * p.groups + g) * tiles + tile) * 2;
+                float* dst = p.stats + (((size_t)b * p.groups + g) * (rows16 * p.tiles_x) + ty16 * p.tiles_x + (tile % p.tiles_x)) * 2;
                 dst[0] = s;
                 dst[1] = ss;
             }
@@ -301,18 +318,34 @@ int conv3x3_db_launch(const dig_conv3x3_args* a, hipStream_t stream) {
     p.bstride0 = a->in0_bstride > 0 ? a->in0_bstride : (long long)(a->up2 ? (a->H / 2) * (a->W / 2) : a->H * a->W) * a->C0;
     p.B = a->B; p.H = a->H; p.W = a->W; p.Cout = a->Cout; p.groups = a->groups; p.up2 = a->up2;
     p.tiles_x = cdiv(a->W, 16);
-    p.tiles_y = cdiv(a->H, TILE_H);
-    static std::atomic<bool> attr_set[64];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    dev &= 63;
-    if (!attr_set[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_db_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS);
-        DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "conv3x3(db): cannot raise dynamic LDS to %d: %s", DB_LDS, hipGetErrorString(e));
-        attr_set[dev].store(true, std::memory_order_release);
+    static std::atomic<int> ncu[64];  // zero-initialised; racing first calls all store the same values
+    int device = 0;
+    (void)hipGetDevice(&device);
+    const int dev = device & 63;
+    int ncus = ncu[dev].load(std::memory_order_acquire);
+    if (!ncus) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<8>::DB_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<4>::DB_LDS);
+        DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "conv3x3(db): cannot raise dynamic LDS to %d: %s", DbCfg<8>::DB_LDS, hipGetErrorString(e));
+        int n = 0;
+        e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device);
+        DIG_CHECK(e == hipSuccess && n > 0, DIG_ELAUNCH, "conv3x3(db): cannot query the CU count");
+        ncu[dev].store(n, std::memory_order_release);
+        ncus = n;
     }
-    dim3 grid(a->B * p.tiles_x * p.tiles_y, a->Cout / BN);
-    hipLaunchKernelGGL(conv3x3_db_kernel, grid, dim3(NTHREADS), DB_LDS, stream, p);
+    // 32-row tiles unless they would leave CUs without a block (one block per CU: 143 KB of LDS); then 16-row tiles, 4 waves
+    const long long grid32 = (long long)a->B * p.tiles_x * cdiv(a->H, 32) * (a->Cout / BN);
+    const char* force = getenv("DIG_DB_TILE");  // test hook, read per call: "16" / "32"
+    const bool small = force ? atoi(force) == 16 : grid32 < ncus;
+    if (small) {
+        p.tiles_y = cdiv(a->H, 16);
+        dim3 grid(a->B * p.tiles_x * p.tiles_y, a->Cout / BN);
+        hipLaunchKernelGGL(conv3x3_db_kernel<4>, grid, dim3(DbCfg<4>::NTHREADS), DbCfg<4>::DB_LDS, stream, p);
+    } else {
+        p.tiles_y = cdiv(a->H, 32);
+        dim3 grid(a->B * p.tiles_x * p.tiles_y, a->Cout / BN);
+        hipLaunchKernelGGL(conv3x3_db_kernel<8>, grid, dim3(DbCfg<8>::NTHREADS), DbCfg<8>::DB_LDS, stream, p);
+    }
     DIG_LAUNCH_CHECK("conv3x3(db)");
     return DIG_OK;
 }

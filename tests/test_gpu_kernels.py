@@ -110,6 +110,28 @@ def test_conv3x3_double_buffered_variants(cfg):
         assert (nchw(y) - ref).abs().max() <= 2 * tol(dt, ref)
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 128, 32, 32), (1, 32, 256, 48, 40), (3, 48, 128, 16, 16), (2, 32, 128, 20, 33)])
+def test_conv3x3_db_tile_heights_bitwise(shape, monkeypatch):
+    """conv3x3_db.hip picks 16-row tiles (4 waves) when 32-row tiles (8 waves) would leave CUs idle, i.e. depending on the
+    batch.  Both must give the same bits - outputs AND GroupNorm partials (one per 16x16 pixels from either height) - or a
+    shard of a batch would not be bitwise equal to the same images inside the full batch.  Ragged heights included."""
+    B, Cin, Co, H, W = shape
+    dt = torch.bfloat16
+    x = nhwc(q(rnd("dbt", (B, Cin, H, W)), dt), dt)
+    w, b = q(rnd("dbtw", (Co, Cin, 3, 3), (3.0 / (9 * Cin)) ** 0.5), dt), rnd("dbtb", (Co,), 0.1)
+    cw = ops.ConvWeight(w.to(DEV), b.to(DEV), dt)
+    aff = torch.stack([1.0 + 0.3 * rnd("dbta", (B, Cin)), 0.2 * rnd("dbtbb", (B, Cin))], -1).to(DEV).contiguous()
+    outs = {}
+    for th in ("16", "32"):
+        monkeypatch.setenv("DIG_DB_TILE", th)
+        outs[th] = ops.conv3x3(x, cw), ops.conv3x3(x, cw, aff=aff)
+    for (y16, s16), (y32, s32) in zip(outs["16"], outs["32"]):
+        assert s16.shape == s32.shape == (B, 8, ((H + 15) // 16) * ((W + 15) // 16), 2)
+        assert torch.equal(y16, y32) and torch.equal(s16, s32)
+    ref = F.conv2d(nchw(x), w, b, padding=1)
+    assert (nchw(outs["16"][0][0]) - ref).abs().max() <= tol(dt, ref)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("mnk", [(300, 200, 64), (128, 64, 32), (37, 3, 64), (5, 520, 256), (1000, 72, 136)])
 def test_gemm_epilogues(dt, mnk):
