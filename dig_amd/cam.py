@@ -25,6 +25,7 @@ def _pack(m):
     P["pe_w"] = f(m.patch_embed.proj.weight.reshape(m.embed_dim, -1))  # [384, 3*16*16], K = (c, ky, kx)
     P["pe_b"] = f(m.patch_embed.proj.bias)
     P["cls"], P["pos"] = f(m.cls_token[0]), f(m.pos_embed[0])
+    P["cls_pos"] = P["cls"] + P["pos"][:m.num_classes]  # class-token rows incl. their (never interpolated) pos-embed, folded at pack time
     P["blocks"] = []
     for blk in m.blocks:
         P["blocks"].append(dict(
@@ -184,15 +185,18 @@ def lfca_forward(L, qkv, C, feat, heads=8):
     return x_c, x_p
 
 
-def mctformer_forward(m, img, n_layers=12, feat_diff=None):
+def mctformer_forward(m, img, n_layers=12, feat_diff=None, flip_tta=False):
     """-> dict with rcams, mtatt, attn (patch_attn), cams, fcams, cls, pcls, feat (mctformer.py:331-350 keys); with
-    feat_diff (five [B,1024,h,w] guidance maps) also cam_diff, diff_cls, diff_pcls (mctformer.py:265-291,324-346)."""
+    feat_diff (five [B,1024,h,w] guidance maps) also cam_diff, diff_cls, diff_pcls (mctformer.py:265-291,324-346).
+    flip_tta: run the batch [img, img.flip(-1)] (2B rows; the mirrored half is formed by the patch im2row kernel)."""
     if not img.is_cuda:
         raise RuntimeError("dig_amd.MCTformerV2_DiG runs on the HIP device only (no CPU fallback)")
     from .diffusion import _same_device
     _same_device(m, img.device, "MCTformerV2_DiG")
     P = _pack(m)
-    B, _, H, W = img.shape
+    Bi, _, H, W = img.shape
+    B = 2 * Bi if flip_tta else Bi
+    assert not (flip_tta and feat_diff is not None)
     C, D, heads, ps = m.num_classes, m.embed_dim, m.num_heads, m.patch_embed.patch_size[0]
     hp, wp = H // ps, W // ps
     Pn, N = hp * wp, C + hp * wp
@@ -201,9 +205,9 @@ def mctformer_forward(m, img, n_layers=12, feat_diff=None):
     pos = _pos_embed(m, P, H, W)
     # patch embedding: im2row + GEMM(+bias, +pos) written straight into the token buffer behind the class tokens
     rows = torch.empty(B * Pn, 3 * ps * ps, dtype=F32, device=dev)
-    call("patchify", img=img, rows=rows, B=B, H=H, W=W, ps=ps)
+    call("patchify", img=img, rows=rows, B=B, H=H, W=W, ps=ps, flip_from=Bi if flip_tta else 0)
     x = torch.empty(B, N, D, dtype=F32, device=dev)
-    x[:, :C] = P["cls"] + pos[:C]  # broadcast copy of the class-token rows
+    x[:, :C] = P["cls_pos"]  # broadcast copy of the class-token rows (cls_token + pos_embed[:C], mctformer.py:240-241)
     ops.gemm_nt(rows, P["pe_w"], (x, C * D), Pn, D, 3 * ps * ps, dtype=F32, bias=P["pe_b"], res=(pos, C * D), ldr=D,
                 batch=B, sa=(Pn * 3 * ps * ps, 0), sc=(N * D, 0), sr=(0, 0))
     acc_all = torch.zeros(B, N, N, dtype=F32, device=dev)
@@ -263,8 +267,7 @@ def infer_multi_cam(m, img, label, n_layers=12):
     img [B,3,H,W] (H, W multiples of 16), label [B,C] -> normalised CAM [B,C,H,W] fp32."""
     B, _, H, W = img.shape
     C = m.num_classes
-    both = torch.cat([img, torch.flip(img, (3,))], 0)  # one batched forward for the image and its flip
-    rc = mctformer_forward(m, both, n_layers)["rcams"]
+    rc = mctformer_forward(m, img, n_layers, flip_tta=True)["rcams"]  # one batched forward for the image and its flip
     hp, wp = rc.shape[-2:]
     out = torch.empty(B, C, H, W, dtype=F32, device=img.device)
     call("cam_tta_norm", rc=rc[:B].contiguous(), rc_flip=rc[B:].contiguous(), label=label.float().contiguous(), out=out,

@@ -20,6 +20,7 @@ namespace {
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // NW = waves per block = 4-row pixel groups per tile: 8 (32x16-pixel tile, the default) or 4 (16x16-pixel tile, for launches
 // whose 32-row tiles would leave CUs idle: e.g. 256->256 at 32x32 with B = 32 is 128 blocks of 8 waves or 256 of 4)
@@ -28,11 +29,18 @@ constexpr int HROW = 512;                               // halo row stride in el
 constexpr int WSLAB_BYTES = 9 * BN * KC * 2;            // 36864
 constexpr int NH = 3;                                   // halo vectors per thread per chunk (NW=8: 34*18*2 = 1224 of 1536 slots; NW=4: 648 of 768)
 constexpr int OS = BN + 4;                              // fp32 staging row stride of the epilogue
-template <int NW> struct DbCfg {
+// DMAH: the halo chunk too goes global -> LDS by LDS-DMA (launches without a GroupNorm/SiLU prologue: nothing has to pass
+// through registers).  Its LDS image is the plain [halo pixel][16 channels] array (32 B per pixel, no row padding); a DMA
+// instruction writes 64 consecutive 16-byte slots, so the bank swizzle is applied on the SOURCE side: slot (pixel, h) holds
+// channel half h ^ bit3(hx), which makes the 16 pixels x 16 B a fragment read touches cover all 64 banks.  Out-of-image
+// pixels are zeroed once (both buffers) and their lanes masked out of every DMA.
+template <int NW, bool DMAH = false> struct DbCfg {
     static constexpr int TILE_H = 4 * NW, HALO_H = TILE_H + 2, NTHREADS = 64 * NW;
-    static constexpr int HALO_BYTES = HALO_H * HROW * 2;           // NW=8: 34816
+    static constexpr int HSLOTS = HALO_H * HALO_W * 2, HPIECES = (HSLOTS + 63) / 64;                 // 16-byte slots, 1 KB DMA pieces
+    static constexpr int HALO_BYTES = DMAH ? HPIECES * 1024 : HALO_H * HROW * 2;                     // NW=8: 20480 / 34816
     static constexpr int BUF_BYTES = HALO_BYTES + WSLAB_BYTES;     // NW=8: 71680
-    static constexpr int DB_LDS = 2 * BUF_BYTES;                   // NW=8: 143360, NW=4: 110592 (the epilogue staging needs NW*32*OS*4 <= that)
+    static constexpr int EPI_BYTES = NW * 32 * (BN + 4) * 4;       // fp32 staging of one output half in the epilogue (NW=8: 135168)
+    static constexpr int DB_LDS = 2 * BUF_BYTES > EPI_BYTES ? 2 * BUF_BYTES : EPI_BYTES;  // NW=8: 143360 (135168 with DMAH), NW=4: 110592 / 96256
 };
 
 #ifndef DB_TAP_ISSUE
@@ -64,9 +72,10 @@ struct DbParams {
     int B, H, W, Cout, groups, up2, tiles_x, tiles_y;
 };
 
-template <int NW> __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(DbParams p) {
-    constexpr int TILE_H = DbCfg<NW>::TILE_H, HALO_H = DbCfg<NW>::HALO_H, NTHREADS = DbCfg<NW>::NTHREADS;
-    constexpr int HALO_BYTES = DbCfg<NW>::HALO_BYTES, BUF_BYTES = DbCfg<NW>::BUF_BYTES;
+template <int NW, bool DMAH> __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(DbParams p) {
+    using Cfg = DbCfg<NW, DMAH>;
+    constexpr int TILE_H = Cfg::TILE_H, HALO_H = Cfg::HALO_H, NTHREADS = Cfg::NTHREADS;
+    constexpr int HALO_BYTES = Cfg::HALO_BYTES, BUF_BYTES = Cfg::BUF_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -138,6 +147,43 @@ template <int NW> __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kerne
             }
         }
     };
+    // ---- DMAH: halo piece q (slots 64q..64q+63) by wave q % NW; per piece the lane's source pixel, channel half and validity
+    constexpr int HPW = (Cfg::HPIECES + NW - 1) / NW;  // pieces per wave (3 for both tile heights)
+    int dpix[HPW];
+    bool dval[HPW];
+    int dhalf[HPW];
+    if constexpr (DMAH) {
+#pragma unroll
+        for (int i = 0; i < HPW; i++) {
+            const int slot = (wave + i * NW) * 64 + lane;
+            const int pix = min(slot >> 1, HALO_H * HALO_W - 1), h = slot & 1;
+            const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
+            const int Y = ty0 + hy - 1, X = tx0 + hx - 1;
+            dval[i] = (wave + i * NW) < Cfg::HPIECES && slot < Cfg::HSLOTS && Y >= 0 && Y < p.H && X >= 0 && X < p.W;
+            const int Yc = min(max(Y, 0), p.H - 1), Xc = min(max(X, 0), p.W - 1);
+            const int sy = p.up2 ? Yc >> 1 : Yc, sx = p.up2 ? Xc >> 1 : Xc;
+            dpix[i] = sy * Ws + sx;
+            dhalf[i] = h ^ ((hx >> 3) & 1);
+            // slots that no DMA ever writes (outside the image, or the tail of the last piece) are zeroed once, in both buffers
+            if (!dval[i] && (wave + i * NW) < Cfg::HPIECES) {
+                *reinterpret_cast<i32x4*>(smem + (wave + i * NW) * 1024 + lane * 16) = i32x4{0, 0, 0, 0};
+                *reinterpret_cast<i32x4*>(smem + BUF_BYTES + (wave + i * NW) * 1024 + lane * 16) = i32x4{0, 0, 0, 0};
+            }
+        }
+    }
+    auto hdma = [&](int ci, unsigned char* buf) {
+        const int piece = ci >= nch0 ? 1 : 0;
+        const int cb = (ci - (piece ? nch0 : 0)) * KC;
+        const int Cp = p.C[piece];
+        const bf16* src = p.in[piece] + (size_t)b * (piece ? (size_t)Hs * Ws * Cp : (size_t)p.bstride0) + cb;
+#pragma unroll
+        for (int i = 0; i < HPW; i++) {
+            if ((wave + i * NW) < Cfg::HPIECES) {  // scalar
+                if (dval[i])                       // lanes of out-of-image pixels stay out of the DMA (EXEC)
+                    __builtin_amdgcn_global_load_lds((glb_void*)(src + (size_t)dpix[i] * Cp + dhalf[i] * 8), (lds_void*)(buf + (wave + i * NW) * 1024), 16, 0, 0);
+            }
+        }
+    };
     // ---- weight chunk: 36 pieces of 1 KB, global -> LDS directly, piece q by wave q % 8
     auto wload = [&](int ci, unsigned char* buf) {
         const unsigned char* slab = wbase + (size_t)ci * WSLAB_BYTES;
@@ -147,8 +193,12 @@ template <int NW> __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kerne
     };
 
     wload(0, smem);
-    gload(0);
-    lstore(0, smem);
+    if constexpr (DMAH) {
+        hdma(0, smem);
+    } else {
+        gload(0);
+        lstore(0, smem);
+    }
     __syncthreads();  // (drains the LDS-DMA as well: vmcnt(0))
     const int bsw = (r >> 3) & 1;  // weight rows with bit 3 set keep their two 16-byte halves swapped
     for (int ci = 0; ci < nch; ci++) {
@@ -175,7 +225,10 @@ template <int NW> __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kerne
 #pragma unroll
             for (int mr = 0; mr < 2; mr++) {
                 const int py = pg * 4 + mr * 2 + (r >> 4), px = r & 15;
-                frag_load<bf16>(fa[mr], halo + (py + ky) * HROW + (px + kx) * KCP + hf * 8);
+                if constexpr (DMAH)
+                    frag_load<bf16>(fa[mr], halo + ((py + ky) * HALO_W + px + kx) * KC + ((hf ^ (((px + kx) >> 3) & 1)) << 3));
+                else
+                    frag_load<bf16>(fa[mr], halo + (py + ky) * HROW + (px + kx) * KCP + hf * 8);
             }
 #pragma unroll
             for (int nr = 0; nr < 4; nr++)
@@ -194,11 +247,14 @@ template <int NW> __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kerne
 #endif
             if (tap == DB_TAP_ISSUE && more) {  // next chunk's loads go out once the MFMA pipe has work queued behind the barrier
                 wload(ci + 1, nxt);
-                gload(ci + 1);
+                if constexpr (DMAH) hdma(ci + 1, nxt);
+                else gload(ci + 1);
             }
             // the halo registers go to LDS inside the MFMA sequence (the partner wave of the SIMD keeps the pipe busy
             // meanwhile); the two wave halves do it at different taps so that they do not all leave the pipe at once
-            if (tap == (wave < NW / 2 ? DB_TAP_STORE_A : DB_TAP_STORE_B) && more) lstore(ci + 1, nxt);
+            if constexpr (!DMAH) {
+                if (tap == (wave < NW / 2 ? DB_TAP_STORE_A : DB_TAP_STORE_B) && more) lstore(ci + 1, nxt);
+            }
         }
         DB_STAMP(2)
         DB_STAMP(3)
@@ -324,8 +380,10 @@ int conv3x3_db_launch(const dig_conv3x3_args* a, hipStream_t stream) {
     const int dev = device & 63;
     int ncus = ncu[dev].load(std::memory_order_acquire);
     if (!ncus) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<8>::DB_LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<4>::DB_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<8>::DB_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<4>::DB_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (DbCfg<8, true>::DB_LDS));
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (DbCfg<4, true>::DB_LDS));
         DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "conv3x3(db): cannot raise dynamic LDS to %d: %s", DbCfg<8>::DB_LDS, hipGetErrorString(e));
         int n = 0;
         e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device);
@@ -337,15 +395,15 @@ int conv3x3_db_launch(const dig_conv3x3_args* a, hipStream_t stream) {
     const long long grid32 = (long long)a->B * p.tiles_x * cdiv(a->H, 32) * (a->Cout / BN);
     const char* force = getenv("DIG_DB_TILE");  // test hook, read per call: "16" / "32"
     const bool small = force ? atoi(force) == 16 : grid32 < ncus;
-    if (small) {
-        p.tiles_y = cdiv(a->H, 16);
-        dim3 grid(a->B * p.tiles_x * p.tiles_y, a->Cout / BN);
-        hipLaunchKernelGGL(conv3x3_db_kernel<4>, grid, dim3(DbCfg<4>::NTHREADS), DbCfg<4>::DB_LDS, stream, p);
-    } else {
-        p.tiles_y = cdiv(a->H, 32);
-        dim3 grid(a->B * p.tiles_x * p.tiles_y, a->Cout / BN);
-        hipLaunchKernelGGL(conv3x3_db_kernel<8>, grid, dim3(DbCfg<8>::NTHREADS), DbCfg<8>::DB_LDS, stream, p);
-    }
+    // halo by LDS-DMA when no prologue has to touch it (DIG_DB_NO_HDMA: test hook, keeps the register-staged path)
+    const bool dmah = a->aff0 == nullptr && getenv("DIG_DB_NO_HDMA") == nullptr;
+    p.tiles_y = cdiv(a->H, small ? 16 : 32);
+    const dim3 grid(a->B * p.tiles_x * p.tiles_y, a->Cout / BN);
+    constexpr int lds4 = DbCfg<4>::DB_LDS, lds4d = DbCfg<4, true>::DB_LDS, lds8 = DbCfg<8>::DB_LDS, lds8d = DbCfg<8, true>::DB_LDS;
+    if (small && dmah) hipLaunchKernelGGL((conv3x3_db_kernel<4, true>), grid, dim3(256), lds4d, stream, p);
+    else if (small) hipLaunchKernelGGL((conv3x3_db_kernel<4, false>), grid, dim3(256), lds4, stream, p);
+    else if (dmah) hipLaunchKernelGGL((conv3x3_db_kernel<8, true>), grid, dim3(512), lds8d, stream, p);
+    else hipLaunchKernelGGL((conv3x3_db_kernel<8, false>), grid, dim3(512), lds8, stream, p);
     DIG_LAUNCH_CHECK("conv3x3(db)");
     return DIG_OK;
 }

@@ -18,7 +18,9 @@ __global__ void patchify_kernel(dig_patchify_args a) {
         const size_t row = i / K;
         const int kx = k % a.ps, ky = (k / a.ps) % a.ps, c = k / (a.ps * a.ps);
         const int px = (int)(row % wp), py = (int)((row / wp) % hp), b = (int)(row / ((size_t)wp * hp));
-        a.rows[i] = a.img[(((size_t)b * 3 + c) * a.H + py * a.ps + ky) * a.W + px * a.ps + kx];
+        const bool mirror = a.flip_from > 0 && b >= a.flip_from;
+        const int sb = mirror ? b - a.flip_from : b, sx = mirror ? a.W - 1 - (px * a.ps + kx) : px * a.ps + kx;
+        a.rows[i] = a.img[(((size_t)sb * 3 + c) * a.H + py * a.ps + ky) * a.W + sx];
     }
 }
 
@@ -556,6 +558,7 @@ inline int grid_for(size_t work, int block, int cap = 256 * 8) {
 extern "C" int dig_patchify(const dig_patchify_args* a, void* stream_) {
     STREAM;
     DIG_CHECK(a && a->img && a->rows && a->ps > 0 && a->H % a->ps == 0 && a->W % a->ps == 0, DIG_EINVAL, "patchify: bad argument");
+    DIG_CHECK(a->B > 0 && (a->flip_from == 0 || a->B == 2 * a->flip_from), DIG_EINVAL, "patchify: flip_from=%d needs B = 2*flip_from, got B=%d", a->flip_from, a->B);
     hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((size_t)a->B * 3 * a->H * a->W, 256)), dim3(256), 0, stream, *a);
     DIG_LAUNCH_CHECK("patchify");
     return DIG_OK;

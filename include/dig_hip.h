@@ -423,11 +423,13 @@ int dig_nhwc_to_nchw_f32(const dig_layout_args* a, void* stream);
 /* ======================= MCTformer class-token attention -> CAM path (fp32 throughout) ======================= */
 
 /* PatchEmbed im2row (networks/vision_transformer.py:238-245): img NCHW fp32 [B][3][H][W] -> rows [B*hp*wp][3*ps*ps],
- * K ordered (c, ky, kx) like the flattened conv weight; followed by dig_gemm_nt with bias (+pos-embed as `res`). */
+ * K ordered (c, ky, kx) like the flattened conv weight; followed by dig_gemm_nt with bias (+pos-embed as `res`).
+ * flip_from > 0: img holds flip_from images and rows of image b >= flip_from come from image b - flip_from mirrored
+ * left-right (the flip-TTA batch torch.cat([img, img.flip(-1)]) of model.py:470-474 without materialising it). */
 typedef struct {
     const float* img;
     float* rows;
-    int B, H, W, ps;
+    int B, H, W, ps, flip_from;
 } dig_patchify_args;
 int dig_patchify(const dig_patchify_args* a, void* stream);
 
