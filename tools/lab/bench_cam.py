@@ -1,6 +1,6 @@
 """Secondary measurement (BASELINE.json configs[2]): MCTformer class-token attention -> CAM path, B images at 224x224, C=20."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dig_amd import cam, synth
 from dig_amd.mctformer import create_model

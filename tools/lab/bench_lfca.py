@@ -1,6 +1,6 @@
 """Secondary measurement: MCTformer forward with the LFCA consumer of the guidance maps, fp32."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dig_amd import synth
 from dig_amd.mctformer import create_model

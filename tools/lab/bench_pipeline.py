@@ -2,7 +2,7 @@
 six Unet passes (five low-t ones batched) -> five guidance maps + the t=100 reconstruction -> MCTformer with the LFCA consumer ->
 MCTformer on the reconstruction -> flip-TTA CAMs -> uint8 labels."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dig_amd import cam, guidance, synth
 from dig_amd.diffusion import GaussianDiffusion, Unet

@@ -1,5 +1,5 @@
 import sys, os, ctypes, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dig_amd import ops, _lib
 dt = torch.bfloat16
 DEV = 'cuda'

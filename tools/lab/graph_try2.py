@@ -1,5 +1,5 @@
 import sys, os, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dig_amd import synth
 from dig_amd.diffusion import GaussianDiffusion, Unet
 torch.set_grad_enabled(False)

@@ -1,5 +1,5 @@
 import sys, os, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dig_amd import ops
 dt = torch.bfloat16
 x = torch.randn(32, 32, 32, 512, device="cuda").to(dt)

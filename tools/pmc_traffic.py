@@ -16,7 +16,7 @@ import sys
 CLASSES = [
     ("conv3x3_ws64", r"conv3x3_ws64_kernel"),
     ("conv3x3_bn128", r"conv3x3_db_kernel|conv3x3_kernelIDF16bLi128"),  # wide layers: double-buffered kernel
-    ("conv3x3_bn64", r"conv3x3_kernelIDF16bLi64"),
+    ("conv3x3_bn64", r"conv3x3_rs128_kernel|conv3x3_kernelIDF16bLi64"),  # 128->64 at 256x256: register-stationary kernel
     ("conv3x3_bn32", r"conv3x3_kernelIDF16bLi32"),
     ("pw_res_k128_n64", r"pw_res_kernel<8"),
     ("pw_res_k192_n128", r"pw_res_kernel<12"),
@@ -30,7 +30,7 @@ CLASSES = [
     ("la_out_c128", r"la_out_kernelIDF16bLi8"),
     ("la_kv_ctx_c256", r"la_kv_ctx_kernelIDF16bLi16"),
     ("la_out_c256", r"la_out_kernelIDF16bLi16"),
-    ("stem", r"stem_kernel"),
+    ("stem", r"stem(64)?_kernel"),
     ("flash_attn", r"flash_attn_kernel"),
 ]
 
