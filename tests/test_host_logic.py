@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for fn in declared:
         assert hasattr(L, fn), fn
     assert L.dig_version() >= 100
-    assert L.dig_conv3x3_tiles(256, 256, 512, 0, 512, 8, 0) == 128 and L.dig_conv3x3_tiles(28, 28, 256, 256, 512, 8, 1) == 4  # bf16 wide: 32x16 tiles
+    assert L.dig_conv3x3_tiles(256, 256, 512, 0, 512, 8, 0) == 256 and L.dig_conv3x3_tiles(28, 28, 256, 256, 512, 8, 1) == 4  # bf16 wide: one partial per 16x16 pixels from either tile height
     assert L.dig_conv3x3_tiles(256, 256, 64, 0, 64, 8, 0) == 1024  # weight-stationary 64->64 variant: per-wave partials
 
 
