@@ -435,7 +435,10 @@ def _unet_forward(u, img, noise, t, sqrt_ac, sqrt_1mac, pre_scale, pre_shift, wa
     With noise=None the stem runs with (1, 0) coefficients, i.e. x_t = pre(img)."""
     if not img.is_cuda:
         raise RuntimeError("dig_amd.Unet runs on the HIP device only (no CPU fallback); move inputs with .cuda()")
-    _same_device(u, img.device, "Unet")
+    P = u.packed()
+    if P.get("device_checked") != img.device:  # once per packing: a move or an in-place update of any parameter re-packs
+        _same_device(u, img.device, "Unet")
+        P["device_checked"] = img.device
     for name, buf in (("noise", noise), ("sqrt_alphas_cumprod", sqrt_ac), ("sqrt_one_minus_alphas_cumprod", sqrt_1mac)):
         if buf is not None and buf.device != img.device:
             raise RuntimeError(f"dig_amd.Unet: {name} lives on {buf.device} but the input on {img.device}; move the "
@@ -443,7 +446,6 @@ def _unet_forward(u, img, noise, t, sqrt_ac, sqrt_1mac, pre_scale, pre_shift, wa
     B, Cin, H, W = img.shape
     f = u.downsample_factor
     assert H % f == 0 and W % f == 0, f"your input dimensions {(H, W)} need to be divisible by {f}, given the unet"
-    P = u.packed()
     dt = P["dtype"]
     dev = img.device
     img = img.contiguous().float()
