@@ -204,3 +204,18 @@ def test_sharded_all_gather_gloo_world2(tmp_path, n):
     for p in procs:
         out, _ = p.communicate(timeout=120)
         assert p.returncode == 0, out.decode()
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """include/dig_hip.h is consumable from C99 and libdig_hip.so links and runs from a C program (no GPU needed for the
+    query / argument-rejection entry points)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = str(tmp_path / "abi")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c_abi_smoke.c"), "-o", exe, "-L", libdir, "-ldig_hip", f"-Wl,-rpath,{libdir}"], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert out.startswith("128 16 ") and "null pointer" in out
