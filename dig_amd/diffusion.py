@@ -430,9 +430,11 @@ def _check_t(t, num_timesteps, B):
     _mark_t_checked(t, num_timesteps)
 
 
-def _unet_forward(u, img, noise, t, sqrt_ac, sqrt_1mac, pre_scale, pre_shift, want_xt, debug=None):
+def _unet_forward(u, img, noise, t, sqrt_ac, sqrt_1mac, pre_scale, pre_shift, want_xt, debug=None, want_pred=True):
     """Shared body of Unet.forward and GaussianDiffusion.p_losses.  img [B,3,H,W] fp32 NCHW.
-    With noise=None the stem runs with (1, 0) coefficients, i.e. x_t = pre(img)."""
+    With noise=None the stem runs with (1, 0) coefficients, i.e. x_t = pre(img).
+    want_pred=False skips final_res_block + final_conv (ddp.py:443-448) and returns pred = None: the guidance loop discards
+    the model output of its five low-t passes (model.py:302,312-314) and the maps do not depend on it."""
     if not img.is_cuda:
         raise RuntimeError("dig_amd.Unet runs on the HIP device only (no CPU fallback); move inputs with .cuda()")
     P = u.packed()
@@ -494,9 +496,11 @@ def _unet_forward(u, img, noise, t, sqrt_ac, sqrt_1mac, pre_scale, pre_shift, wa
         keep(f"ups.{j}.out", x)
         ops.bilinear_ac_into(x, maps, coff)
         coff += chans[j + 1]
-    x = _resnet(P["final_rb"], x, r, ss)
-    pred = torch.empty(B, u.out_dim, H, W, dtype=torch.float32, device=dev)
-    ops.gemm_nt(x, P["final_w"], pred, B * H * W, u.out_dim, u.dim, dtype=dt, bias=P["final_b"], out_f32=True, nchw_hw=H * W)
+    pred = None
+    if want_pred:
+        x = _resnet(P["final_rb"], x, r, ss)
+        pred = torch.empty(B, u.out_dim, H, W, dtype=torch.float32, device=dev)
+        ops.gemm_nt(x, P["final_w"], pred, B * H * W, u.out_dim, u.dim, dtype=dt, bias=P["final_b"], out_f32=True, nchw_hw=H * W)
     feats, o = [], 0
     for c in chans:
         feats.append(maps[:, o:o + c])
@@ -681,10 +685,11 @@ class GaussianDiffusion(nn.Module):
         return self.ddim_sample_from_t((batch_size, self.channels, self.image_size, self.image_size), img, step,
                                        return_all_timesteps=return_all_timesteps, noise=noise)
 
-    def p_losses(self, x_start, t, noise=None, offset_noise_strength=None, pre_scale=(1.0,) * 3, pre_shift=(0.0,) * 3):
+    def p_losses(self, x_start, t, noise=None, offset_noise_strength=None, pre_scale=(1.0,) * 3, pre_shift=(0.0,) * 3, want_pred=True):
         """Eval branch of ddp.py:862-913: returns (x_t, model_out, feat_out).  The discarded MSE of the reference
         (ddp.py:896-909) is not computed.  pre_scale/pre_shift fuse a per-channel affine on x_start into the stem
-        (used by dig_amd.guidance to fold denormforDiff + normalize)."""
+        (used by dig_amd.guidance to fold denormforDiff + normalize).  want_pred=False (not a reference argument): model_out is
+        None and the final ResnetBlock + 1x1 conv that only feed it are skipped - for callers that use the maps alone."""
         if self.model.training:
             raise NotImplementedError("the training loss is outside the guidance path; call .eval() first")
         if noise is None:
@@ -695,7 +700,7 @@ class GaussianDiffusion(nn.Module):
         if x_start.is_cuda:
             _check_t(t, self.num_timesteps, x_start.shape[0])
         pred, feats, x_t = _unet_forward(self.model, x_start, noise, t, self.sqrt_alphas_cumprod,
-                                         self.sqrt_one_minus_alphas_cumprod, pre_scale, pre_shift, want_xt=True)
+                                         self.sqrt_one_minus_alphas_cumprod, pre_scale, pre_shift, want_xt=True, want_pred=want_pred)
         return x_t, pred, feats
 
     def forward(self, img, *args, **kwargs):

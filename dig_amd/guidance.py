@@ -35,14 +35,14 @@ def extract_guidance(diffusion, img, noises=None, t_list=T_LIST, sfi=100, batche
         xs = img.repeat(len(low), 1, 1, 1)
         nz = torch.cat([noises[j] for j in low], 0)
         tt = _mark_t_checked(torch.cat([torch.full((B,), t_list[j], dtype=torch.long, device=dev) for j in low]), diffusion.num_timesteps)
-        diffusion.p_losses(xs, tt, noise=nz, pre_scale=pre_scale, pre_shift=pre_shift)
+        diffusion.p_losses(xs, tt, noise=nz, pre_scale=pre_scale, pre_shift=pre_shift, want_pred=False)  # v of the low-t passes is discarded (model.py:302,312)
         allm = diffusion.model._last_maps
         for i, j in enumerate(low):
             maps[j] = allm[i * B:(i + 1) * B]
     else:
         for j in low:
             tt = _mark_t_checked(torch.full((B,), t_list[j], dtype=torch.long, device=dev), diffusion.num_timesteps)
-            diffusion.p_losses(img, tt, noise=noises[j], pre_scale=pre_scale, pre_shift=pre_shift)
+            diffusion.p_losses(img, tt, noise=noises[j], pre_scale=pre_scale, pre_shift=pre_shift, want_pred=False)
             maps[j] = diffusion.model._last_maps
     img_diff = None
     for j in range(len(t_list)):
