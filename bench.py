@@ -48,6 +48,12 @@ def main():
     ap.add_argument("--profile-kernels", action="store_true", help="per-kernel-class HIP-event breakdown (stderr)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON record: everything the libraries print on fd 1 meanwhile (RCCL's version
+    # banner, for one) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -276,9 +282,13 @@ def main():
                           "image": S, "parallelism": f"dp{world}",
                           "collective": "all_gather_into_tensor(maps fp32 [B,1024,h,w] - fp32 because the maps' consumer (LFCA, model.py:322) and the reference's own feat tensors are fp32), overlapped with the next step" if world > 1 else "none"},
                "whole_forward": whole, "roofline": roof, "cpu_baseline": cpu, "parity": parity}
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if multi:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(json_fd, 1)
+    os.close(json_fd)
 
 
 if __name__ == "__main__":
