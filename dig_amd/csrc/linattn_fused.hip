@@ -153,7 +153,10 @@ __global__ __launch_bounds__(256, (KS * (int)sizeof(T) <= 8 ? LA_KV_WAVES : (KS 
     float m_run = -INFINITY, ksum = 0.f;
     const float sqrtC = sqrtf((float)C);
     // prefetch depth in tiles (register sets are named: static indexing); the wide instantiations have no registers to spare
-    constexpr int PD = (KS * (int)sizeof(T) <= 8) ? 3 : 1;
+#ifndef LA_KV_PD
+#define LA_KV_PD 3
+#endif
+    constexpr int PD = (KS * (int)sizeof(T) <= 8) ? LA_KV_PD : 1;
     Frag<T> pre0[NV], pre1[NV], pre2[NV];
     auto gload = [&](Frag<T>(&pre)[NV], int t) {
 #pragma unroll
@@ -424,7 +427,10 @@ template <typename T, int KS> int launch_out(const dig_la_out_args* a, hipStream
     // C = 256: M_b only (138 KB with the 4 waves' pixel rows), Wq' from L2.  fp32 storage keeps both in L2 above C = 64.
     constexpr bool BF = sizeof(T) == 2;
     constexpr bool WQL = KS <= 4 || (BF && KS == 8), MBL = KS <= 4 || (BF && KS >= 8);
-    constexpr int NW = (BF && KS == 8) ? 8 : 4;
+#ifndef LA_OUT_NW64
+#define LA_OUT_NW64 8  // C = 64: 8 waves per block, two blocks per CU = 4 waves per SIMD (120 VGPRs): the per-wave chain LDS -> MFMA ->
+#endif                 // softmax -> MFMA -> RMSNorm -> store is latency bound; 165 -> 140 us at 256x256 against 4-wave blocks
+    constexpr int NW = (BF && KS == 8) ? 8 : ((BF && KS == 4) ? LA_OUT_NW64 : 4);
     size_t lds = (size_t)NW * 32 * (C + 8) * sizeof(T) + 2 * DT * 32 * sizeof(float);
     if (WQL) lds += (size_t)128 * (C + 8) * sizeof(T);
     if (MBL) lds += (size_t)DT * 32 * 136 * sizeof(T);
