@@ -90,7 +90,10 @@ __device__ __forceinline__ void attn_tile(const T* ks, const T* vs, const Frag<T
         }
 }
 
-template <typename T> __global__ __launch_bounds__(256, 2) void flash_attn_kernel(dig_flash_attn_args a) {
+#ifndef FA_BLOCKS
+#define FA_BLOCKS 2
+#endif
+template <typename T> __global__ __launch_bounds__(256, FA_BLOCKS) void flash_attn_kernel(dig_flash_attn_args a) {
     using Cfg = AttnCfg<T>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* ks = reinterpret_cast<T*>(smem);   // [KT][KRS]
