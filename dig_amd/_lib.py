@@ -155,3 +155,15 @@ def dtype_code(torch_dtype):
     if torch_dtype == torch.float32:
         return DIG_F32
     raise ValueError(f"unsupported dtype {torch_dtype}; the HIP path stores activations as bfloat16 or float32")
+
+
+def _tver(t):
+    """Version counter of a tensor, 0 for an inference tensor: tensors created under torch.inference_mode() (the reference
+    decorates sample_from_t / ddim_sample_from_t with it, ddp.py:770,827) track no version and raise on `_version`; they
+    cannot be written in place outside inference mode either, so a constant is a sound stand-in for the cache key."""
+    return 0 if t.is_inference() else t._version
+
+
+def _pver(params):
+    """Sum of the parameters' version counters (the re-pack key); inference tensors count 0, see _tver."""
+    return sum(_tver(q) for q in params)

@@ -11,13 +11,13 @@ import math
 import torch
 
 from . import ops
-from ._lib import call
+from ._lib import _pver, call
 
 F32 = torch.float32
 
 
 def _pack(m):
-    key = (next(m.parameters()).device, sum(p._version for p in m.parameters()), m.cls_token.data_ptr())
+    key = (next(m.parameters()).device, _pver(m.parameters()), m.cls_token.data_ptr())
     if m._packed is not None and m._packed["key"] == key:
         return m._packed
     f = lambda t: t.detach().float().contiguous()
@@ -68,7 +68,7 @@ def _pos_embed(m, P, H, W):
 
 def _pack_lfca(m):
     dt = m.lfca_dtype
-    key = (next(m.parameters()).device, sum(p._version for p in m.parameters()), m.LFCA0.query.weight.data_ptr(), dt)
+    key = (next(m.parameters()).device, _pver(m.parameters()), m.LFCA0.query.weight.data_ptr(), dt)
     if m._packed_lfca is not None and m._packed_lfca["key"] == key:
         return m._packed_lfca
     f = lambda t: t.detach().float().contiguous()

@@ -242,6 +242,19 @@ template <int NW, bool DMAH> __global__ __launch_bounds__(64 * NW, 2) void conv3
             for (int mr = 0; mr < 2; mr++) asm volatile("" ::"v"(fa[mr].v));
 #pragma unroll
             for (int nr = 0; nr < 4; nr++) asm volatile("" ::"v"(fb[nr].v));
+#elif defined(DB_MFMA16)  // ablation build (wrong results): the same fragment reads feeding v_mfma_f32_16x16x32_bf16, 16 per tap
+#pragma unroll
+            for (int mr = 0; mr < 2; mr++)
+#pragma unroll
+                for (int nr = 0; nr < 4; nr++)
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const int sub = (tap & 1) * 2 + q;
+                        f32x4 t = {acc[mr][nr][4 * sub], acc[mr][nr][4 * sub + 1], acc[mr][nr][4 * sub + 2], acc[mr][nr][4 * sub + 3]};
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mr].v, fb[nr].v, t, 0, 0, 0);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) acc[mr][nr][4 * sub + e] = t[e];
+                    }
 #else
 #pragma unroll
             for (int mr = 0; mr < 2; mr++)

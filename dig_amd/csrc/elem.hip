@@ -246,6 +246,94 @@ template <typename T> __global__ void sinusoid_kernel(dig_sinusoid_args a) {
     ((T*)a.out)[i] = from_f32<T>(j < half ? sinf(ang) : cosf(ang));
 }
 
+// Fused head of the time embedding (ddp.py:118-130,316-321): sinusoid -> Linear(dim, tdim) -> GELU(erf) -> Linear(tdim, tdim),
+// one block per image; writes temb and SiLU(temb) (the input of every block's `mlp`, ddp.py:172-175).  fp32 throughout.
+__global__ __launch_bounds__(1024) void time_embed_kernel(dig_time_embed_args a) {
+    extern __shared__ float te_sm[];
+    float* emb = te_sm;          // [dim]
+    float* e1 = te_sm + a.dim;   // [tdim]
+    const int b = blockIdx.x, tid = threadIdx.x, half = a.dim / 2;
+    for (int j = tid; j < a.dim; j += 1024) {
+        const int fi = j < half ? j : j - half;
+        const float freq = expf((float)fi * -(logf(10000.0f) / (float)(half - 1)));  // as sinusoid_kernel
+        const float ang = (float)a.t[b] * freq;
+        emb[j] = j < half ? sinf(ang) : cosf(ang);
+    }
+    __syncthreads();
+    // rows of W are split over G adjacent lanes (16-byte loads, whole rows coalesced), 64 / G rows per wave instruction, and
+    // the loads of 8 row groups (x 16 waves: half the rows of a 256-wide layer) are issued before the first is used (a block is one dependent chain: L2 latency is all it waits for)
+    const int lane = tid & 63, wave = tid >> 6;
+    auto matvec = [&](const float* __restrict__ W, const float* __restrict__ bias, const float* x, int K, auto&& emit) {
+        const int G = K / 4 < 64 ? K / 4 : 64, rp = 64 / G, gl = lane % G, gr = lane / G;
+        for (int n0 = wave * rp; n0 < a.tdim; n0 += 16 * rp * 8) {
+            float acc[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc[u] = 0.f;
+            for (int k = gl * 4; k < K; k += G * 4) {
+                f32x4 w4[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) w4[u] = *reinterpret_cast<const f32x4*>(W + (size_t)min(n0 + u * 16 * rp + gr, a.tdim - 1) * K + k);
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    acc[u] = fmaf(w4[u][0], x[k], acc[u]); acc[u] = fmaf(w4[u][1], x[k + 1], acc[u]);
+                    acc[u] = fmaf(w4[u][2], x[k + 2], acc[u]); acc[u] = fmaf(w4[u][3], x[k + 3], acc[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                for (int o = G >> 1; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o, 64);
+                const int n = n0 + u * 16 * rp + gr;
+                if (n < a.tdim && gl == 0) emit(n, acc[u] + bias[n]);
+            }
+        }
+    };
+    matvec(a.w1, a.b1, emb, a.dim, [&](int n, float v) { e1[n] = gelu_erf_f(v); });
+    __syncthreads();
+    float* __restrict__ temb = a.temb + (size_t)b * a.tdim;
+    float* __restrict__ st = a.st + (size_t)b * a.tdim;
+    matvec(a.w3, a.b3, e1, a.tdim, [&](int n, float v) {
+        temb[n] = v;
+        st[n] = silu_f(v);
+    });
+}
+
+// All per-block time projections in one skinny GEMM (ddp.py:172-175,186-188 for the 19 ResnetBlocks at once):
+// out[b][n] = bias[n] + sum_k st[b][k] W[n][k], B <= a few hundred rows, N = sum 2*C_out (8064), K = tdim (256).
+// One wave per 32 rows x 32 columns, exact fp32 on v_mfma_f32_32x32x2_f32, operands straight from L2 (32-byte runs per lane).
+__global__ __launch_bounds__(64) void time_mlp_kernel(dig_time_mlp_args a) {
+    const int lane = threadIdx.x, r = lane & 31, hf = lane >> 5;
+    const int n0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int row = b0 + r, col = n0 + r;
+    const bool rv = row < a.B, cv = col < a.N;
+    const float* ap = a.st + (size_t)(rv ? row : 0) * a.K + hf * 8;
+    const float* bp = a.w + (size_t)(cv ? col : 0) * a.K + hf * 8;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+    for (int k0 = 0; k0 < a.K; k0 += 64) {
+        Frag<float> fa[4], fb[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            frag_load<float>(fa[s], ap + k0 + s * 16);
+            frag_load<float>(fb[s], bp + k0 + s * 16);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            if (!rv) frag_zero<float>(fa[s]);
+            if (!cv) frag_zero<float>(fb[s]);
+            mma16<float>(acc, fa[s], fb[s]);
+        }
+    }
+    if (cv) {
+        const float bias = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int rr = b0 + acc_row(e, lane);
+            if (rr < a.B) a.out[(size_t)rr * a.N + col] = acc[e] + bias;
+        }
+    }
+}
+
 template <typename TI, typename TO> __global__ void act_kernel(const TI* in, TO* out, long long n, int act) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float x = (float)in[i];
@@ -414,6 +502,28 @@ extern "C" int dig_sinusoid(const dig_sinusoid_args* a, void* stream_) {
     if (a->dtype == DIG_BF16) hipLaunchKernelGGL(sinusoid_kernel<bf16>, dim3(g), dim3(256), 0, stream, *a);
     else hipLaunchKernelGGL(sinusoid_kernel<float>, dim3(g), dim3(256), 0, stream, *a);
     DIG_LAUNCH_CHECK("sinusoid");
+    return DIG_OK;
+}
+
+extern "C" int dig_time_embed(const dig_time_embed_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->t && a->w1 && a->b1 && a->w3 && a->b3 && a->temb && a->st, DIG_EINVAL, "time_embed: null pointer");
+    auto okw = [](int k) { return k >= 4 && k % 4 == 0 && (k % 256 == 0 || (k <= 256 && ((k / 4) & (k / 4 - 1)) == 0)); };
+    DIG_CHECK(a->B > 0 && okw(a->dim) && okw(a->tdim) && (a->dim + a->tdim) * 4 <= 48 * 1024, DIG_EINVAL,
+              "time_embed: needs B > 0 and dim, tdim each a power of two in [4, 256] or a multiple of 256 (got B=%d dim=%d tdim=%d)", a->B, a->dim, a->tdim);
+    DIG_CHECK(((uintptr_t)a->w1 | (uintptr_t)a->w3) % 16 == 0, DIG_EALIGN, "time_embed: weights must be 16-byte aligned");
+    hipLaunchKernelGGL(time_embed_kernel, dim3(a->B), dim3(1024), (size_t)(a->dim + a->tdim) * 4, stream, *a);
+    DIG_LAUNCH_CHECK("time_embed");
+    return DIG_OK;
+}
+
+extern "C" int dig_time_mlp(const dig_time_mlp_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->st && a->w && a->out, DIG_EINVAL, "time_mlp: null pointer");
+    DIG_CHECK(a->B > 0 && a->N > 0 && a->K > 0 && a->K % 64 == 0, DIG_EINVAL, "time_mlp: needs K %% 64 == 0 (got B=%d N=%d K=%d)", a->B, a->N, a->K);
+    DIG_CHECK(((uintptr_t)a->st | (uintptr_t)a->w) % 16 == 0, DIG_EALIGN, "time_mlp: st / w must be 16-byte aligned");
+    hipLaunchKernelGGL(time_mlp_kernel, dim3(cdiv(a->N, 32), cdiv(a->B, 32)), dim3(64), 0, stream, *a);
+    DIG_LAUNCH_CHECK("time_mlp");
     return DIG_OK;
 }
 

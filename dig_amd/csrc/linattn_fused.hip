@@ -293,6 +293,56 @@ template <typename T> __global__ __launch_bounds__(256) void la_merge_kernel(dig
     out[d * 32 + e] = from_f32<T>(num / den);
 }
 
+// merge + M_b in one launch (one 1024-thread block per (image, head)): the merged context stays in LDS (rounded through the
+// storage type, as the stand-alone merge stores it) and M_b[c][h*32+d] = sum_e Wout[c][h*32+e] ctx[d][e] (ddp.py:231 folded
+// into to_out) is formed right there - two launches (la_merge 19 us + a 128-problem batched GEMM 10 us) become one of a few us.
+#define LA_MAX_SPLITS 32
+template <typename T> __global__ __launch_bounds__(1024) void la_merge_mb_kernel(dig_la_merge_args a) {
+    __shared__ float cs[32 * 33];
+    const int bh = blockIdx.x, b = bh / 4, h = bh % 4;
+    const int i = threadIdx.x, e = i >> 5, d = i & 31;
+    // all loads of the (at most LA_MAX_SPLITS) splits are issued before anything is used: the chain was one L2 round trip per split
+    float pm[LA_MAX_SPLITS], pt[LA_MAX_SPLITS], ps[LA_MAX_SPLITS];
+#pragma unroll
+    for (int s = 0; s < LA_MAX_SPLITS; s++) {
+        const size_t slot = ((size_t)b * a.splits + min(s, a.splits - 1)) * 4 + h;
+        pm[s] = a.pmax[slot * 32 + d];
+        pt[s] = a.part[slot * 1024 + i];
+        ps[s] = a.psum[slot * 32 + d];
+    }
+    float M = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < LA_MAX_SPLITS; s++)
+        if (s < a.splits) M = fmaxf(M, pm[s]);
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int s = 0; s < LA_MAX_SPLITS; s++) {  // same order and arithmetic as la_merge_kernel: the two give identical contexts
+        if (s < a.splits) {
+            const float w = __expf(pm[s] - M);
+            num += w * pt[s];
+            den += w * ps[s];
+        }
+    }
+    const T v = from_f32<T>(num / den);
+    if (a.ctx) ((T*)a.ctx)[(size_t)bh * 1024 + d * 32 + e] = v;
+    cs[d * 33 + e] = to_f32<T>(v);
+    __syncthreads();
+    const T* wo = (const T*)a.wo;
+    T* mb = (T*)a.mb + (size_t)b * a.dim * 128;
+    for (int idx = i; idx < a.dim * 32; idx += 1024) {
+        const int c = idx >> 5, dd = idx & 31;
+        float acc = 0.f;
+#pragma unroll
+        for (int v8 = 0; v8 < 4; v8++) {
+            Frag<T> f;
+            frag_load<T>(f, wo + (size_t)c * 128 + h * 32 + v8 * 8);
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc = fmaf(frag_get<T>(f, j), cs[dd * 33 + v8 * 8 + j], acc);
+        }
+        mb[(size_t)c * 128 + h * 32 + dd] = from_f32<T>(acc);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // pass B.  One wave owns 32 pixels at a time (its own 32 rows of the LDS tile - no block barriers in the loop) and
 // walks `iters` such sub-tiles of one image.  Where they fit (WQL / MBL, see launch_out) the q weights and this image's
@@ -524,7 +574,15 @@ extern "C" int dig_la_kvctx(const dig_la_kvctx_args* a, void* stream_) {
 
 extern "C" int dig_la_merge(const dig_la_merge_args* a, void* stream_) {
     hipStream_t st = (hipStream_t)stream_;
-    DIG_CHECK(a && a->part && a->pmax && a->psum && a->ctx && a->B > 0 && a->splits > 0, DIG_EINVAL, "la_merge: bad argument");
+    DIG_CHECK(a && a->part && a->pmax && a->psum && (a->ctx || a->mb) && a->B > 0 && a->splits > 0, DIG_EINVAL, "la_merge: bad argument");
+    if (a->mb) {
+        DIG_CHECK(a->wo && a->dim > 0 && a->splits <= LA_MAX_SPLITS, DIG_EINVAL, "la_merge: M_b output needs wo, dim and splits <= %d", LA_MAX_SPLITS);
+        DIG_CHECK(((uintptr_t)a->wo | (uintptr_t)a->mb) % 16 == 0, DIG_EALIGN, "la_merge: wo / mb must be 16-byte aligned");
+        if (a->dtype == DIG_BF16) hipLaunchKernelGGL(la_merge_mb_kernel<bf16>, dim3(a->B * 4), dim3(1024), 0, st, *a);
+        else hipLaunchKernelGGL(la_merge_mb_kernel<float>, dim3(a->B * 4), dim3(1024), 0, st, *a);
+        DIG_LAUNCH_CHECK("la_merge(mb)");
+        return DIG_OK;
+    }
     if (a->dtype == DIG_BF16) hipLaunchKernelGGL(la_merge_kernel<bf16>, dim3(a->B * 4, 4), dim3(256), 0, st, *a);
     else hipLaunchKernelGGL(la_merge_kernel<float>, dim3(a->B * 4, 4), dim3(256), 0, st, *a);
     DIG_LAUNCH_CHECK("la_merge");
@@ -577,6 +635,7 @@ extern "C" int dig_la_ctx_noalloc(const dig_la_ctx_noalloc_args* a, void* stream
     if (rc != DIG_OK) return rc;
     dig_la_merge_args m;
     m.part = k.part; m.pmax = k.pmax; m.psum = k.psum; m.ctx = a->ctx; m.B = a->B; m.splits = a->splits; m.dtype = a->dtype;
+    m.wo = nullptr; m.mb = nullptr; m.dim = 0;
     (void)st;
     return dig_la_merge(&m, stream_);
 }

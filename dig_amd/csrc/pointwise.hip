@@ -12,7 +12,11 @@
 
 namespace {
 
-template <int KS, int NT>
+// FIN: the block is the Unet's final_res_block and the 1x1 final_conv (ddp.py:373,443-448: N -> f_no <= 4 channels, fp32 NCHW) is
+// applied to the fp32 result while it is still in the accumulator layout: the block's output never goes to HBM (at 256x256 a
+// 268 MB write + read and one launch).  Lane (pixel r, half hf) owns 32 of the pixel's 64 channels; one xor-32 shuffle
+// completes the dot products.
+template <int KS, int NT, bool FIN>
 __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void pw_res_kernel(dig_pw_res_args a, int iters) {
     constexpr int K = KS * 16, N = NT * 32, KP = K + 8, NP = N + 8;
     constexpr int NVX = K / 16, NVG = N / 16;  // 16-byte vectors per lane per sub-tile: x rows, h2 rows
@@ -22,6 +26,7 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void pw_res_kernel(dig_pw_r
     float* aff_l = bias_l + N;                                      // [4 waves][N][2]
     bf16* xs_all = reinterpret_cast<bf16*>(aff_l + 4 * N * 2);      // [4 waves][32][KP]
     bf16* gs_all = xs_all + 4 * 32 * KP;                            // [4 waves][32][NP]
+    float* fw_l = reinterpret_cast<float*>(gs_all + 4 * 32 * NP);   // FIN: [4][N] final_conv weights (rows >= f_no zero)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hf = lane >> 5;
@@ -36,6 +41,8 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void pw_res_kernel(dig_pw_r
         *reinterpret_cast<bf16x8*>(ws + n * KP + v * 8) = *reinterpret_cast<const bf16x8*>((const bf16*)a.w + (size_t)n * K + v * 8);
     }
     for (int i = tid; i < N; i += 256) bias_l[i] = a.bias ? a.bias[i] : 0.f;
+    if constexpr (FIN)
+        for (int i = tid; i < 4 * N; i += 256) fw_l[i] = i < a.f_no * N ? a.fw[i] : 0.f;
     __syncthreads();
 
     bf16* xs = xs_all + wave * 32 * KP;
@@ -108,6 +115,7 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void pw_res_kernel(dig_pw_r
             }
         }
         // + SiLU(a h2 + b), in place over the h2 rows (pixel r of this lane, channels ct*32 + 8 q4 + 4 hf + 0..3)
+        float fd[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ct = 0; ct < NT; ct++)
 #pragma unroll
@@ -120,8 +128,31 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void pw_res_kernel(dig_pw_r
                 const float v1 = acc[ct][4 * q4 + 1] + silu_f(ab0[2] * (float)g[1] + ab0[3]);
                 const float v2 = acc[ct][4 * q4 + 2] + silu_f(ab1[0] * (float)g[2] + ab1[1]);
                 const float v3 = acc[ct][4 * q4 + 3] + silu_f(ab1[2] * (float)g[3] + ab1[3]);
-                *reinterpret_cast<bf16x4*>(gp) = bf16x4{(bf16)v0, (bf16)v1, (bf16)v2, (bf16)v3};
+                if constexpr (FIN) {
+                    const float v[4] = {v0, v1, v2, v3};
+#pragma unroll
+                    for (int o = 0; o < 4; o++) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(fw_l + o * N + c0);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) fd[o] += w4[j] * v[j];
+                    }
+                } else {
+                    *reinterpret_cast<bf16x4*>(gp) = bf16x4{(bf16)v0, (bf16)v1, (bf16)v2, (bf16)v3};
+                }
             }
+        if constexpr (FIN) {
+            // fout[img][o][pixel]: lanes of half hf store planes o = hf and hf + 2 (32 consecutive pixels = 128 bytes each)
+            const long long row = sub * 32 + r;
+            const long long im = row / a.rows_per_img, pix = row - im * a.rows_per_img;
+#pragma unroll
+            for (int o = 0; o < 4; o++) fd[o] += __shfl_xor(fd[o], 32, 64);
+#pragma unroll
+            for (int oo = 0; oo < 2; oo++) {
+                const int o = hf + 2 * oo;
+                if (o < a.f_no) a.fout[(im * a.f_no + o) * a.rows_per_img + pix] = (hf ? fd[1 + 2 * oo] : fd[2 * oo]) + a.fb[o];
+            }
+            continue;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -135,17 +166,17 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void pw_res_kernel(dig_pw_r
 
 template <int KS, int NT> size_t pw_lds() {
     constexpr int K = KS * 16, N = NT * 32;
-    return (size_t)N * (K + 8) * 2 + (size_t)N * 4 + (size_t)4 * N * 2 * 4 + (size_t)4 * 32 * (K + 8) * 2 + (size_t)4 * 32 * (N + 8) * 2;
+    return (size_t)N * (K + 8) * 2 + (size_t)N * 4 + (size_t)4 * N * 2 * 4 + (size_t)4 * 32 * (K + 8) * 2 + (size_t)4 * 32 * (N + 8) * 2 + (size_t)4 * N * 4;
 }
 
-template <int KS, int NT> int launch(const dig_pw_res_args* a, hipStream_t st) {
+template <int KS, int NT, bool FIN = false> int launch(const dig_pw_res_args* a, hipStream_t st) {
     const size_t lds = pw_lds<KS, NT>();
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
     dev &= 63;
     if (!attr_set[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void*)pw_res_kernel<KS, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)pw_res_kernel<KS, NT, FIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "pw_res: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
         attr_set[dev].store(true, std::memory_order_release);
     }
@@ -154,7 +185,7 @@ template <int KS, int NT> int launch(const dig_pw_res_args* a, hipStream_t st) {
     int iters = (int)(groups / 1024);
     iters = iters < 1 ? 1 : (iters > 16 ? 16 : iters);
     const long long grid = (groups + iters - 1) / iters;
-    hipLaunchKernelGGL((pw_res_kernel<KS, NT>), dim3((unsigned)grid), dim3(256), lds, st, *a, iters);
+    hipLaunchKernelGGL((pw_res_kernel<KS, NT, FIN>), dim3((unsigned)grid), dim3(256), lds, st, *a, iters);
     DIG_LAUNCH_CHECK("pw_res");
     return DIG_OK;
 }
@@ -169,12 +200,18 @@ extern "C" int dig_pw_res_supported(int K0, int K1, int N, int dtype) {
 
 extern "C" int dig_pw_res(const dig_pw_res_args* a, void* stream_) {
     hipStream_t st = (hipStream_t)stream_;
-    DIG_CHECK(a && a->x0 && a->w && a->gsrc && a->gaff && a->out, DIG_EINVAL, "pw_res: null pointer");
+    DIG_CHECK(a && a->x0 && a->w && a->gsrc && a->gaff && (a->out || a->fout), DIG_EINVAL, "pw_res: null pointer");
+    if (a->fout) {
+        DIG_CHECK(a->fw && a->fb && a->f_no >= 1 && a->f_no <= 4, DIG_EINVAL, "pw_res: the fused final conv needs fw, fb and 1 <= f_no <= 4 (got %d)", a->f_no);
+        DIG_CHECK(a->K0 + a->K1 == 128 && a->N == 64, DIG_EINVAL, "pw_res: the fused final conv is built for K0+K1 = 128, N = 64");
+        DIG_CHECK(((uintptr_t)a->fw | (uintptr_t)a->fb | (uintptr_t)a->fout) % 4 == 0, DIG_EALIGN, "pw_res: fw / fb / fout must be 4-byte aligned");
+    }
     DIG_CHECK(a->K1 == 0 || a->x1, DIG_EINVAL, "pw_res: K1 > 0 needs x1");
     DIG_CHECK(dig_pw_res_supported(a->K0, a->K1, a->N, a->dtype), DIG_EINVAL, "pw_res: unsupported shape K0=%d K1=%d N=%d dtype=%d", a->K0, a->K1, a->N, a->dtype);
     DIG_CHECK(a->M > 0 && a->M % 32 == 0 && a->rows_per_img > 0 && a->rows_per_img % 32 == 0, DIG_EINVAL, "pw_res: M and rows_per_img must be multiples of 32");
     DIG_CHECK(((uintptr_t)a->x0 | (uintptr_t)a->x1 | (uintptr_t)a->w | (uintptr_t)a->gsrc | (uintptr_t)a->gaff | (uintptr_t)a->out) % 16 == 0, DIG_EALIGN,
               "pw_res: pointers must be 16-byte aligned");
+    if (a->fout) return launch<8, 2, true>(a, st);
     if (a->K0 + a->K1 == 128) return launch<8, 2>(a, st);
     return launch<12, 4>(a, st);
 }

@@ -23,7 +23,7 @@ import torch
 from torch import nn
 
 from . import ops
-from ._lib import call, dtype_code
+from ._lib import _pver, _tver, call, dtype_code
 
 __all__ = ["Unet", "GaussianDiffusion", "Attend", "sigmoid_beta_schedule"]
 
@@ -182,7 +182,7 @@ class Unet(nn.Module):
 
     def _pack_key(self):
         p = next(self.parameters())
-        return (p.device, self.compute_dtype, sum(q._version for q in self.parameters()), p.data_ptr())
+        return (p.device, self.compute_dtype, _pver(self.parameters()), p.data_ptr())
 
     def packed(self):
         key = self._pack_key()
@@ -278,6 +278,7 @@ def _pack_unet(u, dt):
     P["ups"] = [stage(s, False, (dims[n - 1 - j], dims[n - 1 - j])) for j, s in enumerate(u.ups)]
     P["final_rb"] = rb(u.final_res_block, u.dim)
     P["final_w"], P["final_b"] = _conv1_pack(u.final_conv, dt)
+    P["final_w32"] = u.final_conv.weight.detach().float().reshape(u.final_conv.weight.shape[0], -1).contiguous()
     P["mlp_w"], P["mlp_b"] = torch.cat(mlps_w, 0).contiguous(), torch.cat(mlps_b, 0).contiguous()
     dev = u.init_conv.weight.device
     P["one"] = torch.ones(1, dtype=torch.float32, device=dev)
@@ -288,8 +289,9 @@ def _pack_unet(u, dt):
 # --------------------------------------------------------------------------------------------------
 # forward building blocks (all on the current HIP stream)
 # --------------------------------------------------------------------------------------------------
-def _resnet(p, x0, x1, ss_all, debug=None):
-    """ResnetBlock (ddp.py:169-194); x1 = second half of a fused channel concat (or None)."""
+def _resnet(p, x0, x1, ss_all, debug=None, final=None):
+    """ResnetBlock (ddp.py:169-194); x1 = second half of a fused channel concat (or None).
+    final = (fw, fb, pred): fuse the Unet's final_conv into the block tail (ops.res_tail); returns None then."""
     hw = x0.shape[1] * x0.shape[2]
     c1, st1 = ops.conv3x3(x0, p["w1"], x1=x1)
     aff1 = ops.gn_finalize(st1, p["g1"], p["be1"], hw, ss=ss_all, ss_off=p["ss_off"], eps=p["eps"])
@@ -299,7 +301,7 @@ def _resnet(p, x0, x1, ss_all, debug=None):
         assert x1 is None
         return ops.gn_silu_add(c2, aff2, res=x0)
     wr, br = p["res"]
-    return ops.res_tail(x0, wr, br, x1, c2, aff2, hw)
+    return ops.res_tail(x0, wr, br, x1, c2, aff2, hw, final=final)
 
 
 def _linear_attention_unfused(p, x):
@@ -361,11 +363,9 @@ def _linear_attention(p, x):
     pmax = torch.empty(B, splits, 4, 32, dtype=torch.float32, device=x.device)
     psum = torch.empty(B, splits, 4, 32, dtype=torch.float32, device=x.device)
     call("la_kvctx", x=x, wkv=p["wkv_g"], part=part, pmax=pmax, psum=psum, B=B, n=n, C=C, hid=128, splits=splits, dtype=dc)
-    ctx = torch.empty(B * 4, 32, 32, dtype=dt, device=x.device)  # [bh][d][e]
-    call("la_merge", part=part, pmax=pmax, psum=psum, ctx=ctx, B=B, splits=splits, dtype=dc)
+    # merge of the splits and M_b = Wout . blockdiag(ctx^T) in ONE launch (the context itself never goes to HBM)
     Mb = torch.empty(B, dim, 128, dtype=dt, device=x.device)
-    ops.gemm_nt(p["wo"], ctx, Mb, dim, 32, 32, dtype=dt, lda0=128, ldb=32, ldc=128, batch=B * 4, z_inner=4,
-                sa=(0, 32), sb=(4 * 1024, 1024), sc=(dim * 128, 32))
+    call("la_merge", part=part, pmax=pmax, psum=psum, ctx=None, B=B, splits=splits, dtype=dc, wo=p["wo"], mb=Mb, dim=dim)
     out = torch.empty_like(x)
     call("la_out", x=x, wq=p["wq_g"], mb=Mb, bias=p["bo"], g2=p["g2"], out=out, B=B, n=n, C=C, dim=dim, dtype=dc, scale=32 ** -0.5)
     return out
@@ -388,7 +388,24 @@ def _full_attention(p, x):
 
 
 def _time_embedding(u, P, t):
-    """ddp.py:118-130,316-321 and every block's SiLU+Linear (ddp.py:172-175,186-188); always fp32 (tiny)."""
+    """ddp.py:118-130,316-321 and every block's SiLU+Linear (ddp.py:172-175,186-188); always fp32 (tiny).  Two launches:
+    sinusoid + both Linears + GELU/SiLU per image, then all 19 block projections as one skinny GEMM."""
+    B = t.shape[0]
+    tdim = P["t3"][0].shape[0]
+    okw = lambda k: k >= 4 and k % 4 == 0 and (k % 256 == 0 or (k <= 256 and (k // 4) & (k // 4 - 1) == 0))
+    if not (okw(u.dim) and okw(tdim)) or tdim % 64:  # widths the fused kernels do not take (dig_time_embed, dig_time_mlp)
+        return _time_embedding_unfused(u, P, t)
+    temb = torch.empty(B, tdim, dtype=torch.float32, device=t.device)
+    st = torch.empty_like(temb)
+    call("time_embed", t=t, w1=P["t1"][0], b1=P["t1"][1], w3=P["t3"][0], b3=P["t3"][1], temb=temb, st=st, B=B, dim=u.dim, tdim=tdim)
+    N = P["mlp_w"].shape[0]
+    ss = torch.empty(B, N, dtype=torch.float32, device=t.device)
+    call("time_mlp", st=st, w=P["mlp_w"], bias=P["mlp_b"], out=ss, B=B, N=N, K=tdim)
+    return temb, ss  # [B, sum 2*C] fp32
+
+
+def _time_embedding_unfused(u, P, t):
+    """The same chain on the general kernels (widths the fused kernels do not take)."""
     B = t.shape[0]
     emb = torch.empty(B, u.dim, dtype=torch.float32, device=t.device)
     call("sinusoid", t=t, out=emb, B=B, dim=u.dim, dtype=dtype_code(torch.float32))
@@ -410,8 +427,10 @@ def _same_device(module, dev, what):
 
 def _mark_t_checked(t, num_timesteps):
     """Remember on the tensor OBJECT (not its storage address, which the allocator reuses) that its current version holds
-    valid timesteps; an in-place write bumps _version and voids the mark."""
-    t._dig_t_ok = (t._version, num_timesteps)
+    valid timesteps; an in-place write bumps _version and voids the mark.  Called directly only on tensors this package has
+    just built from Python ints and never writes again (also under torch.inference_mode(), where there is no version
+    counter); _check_t does not mark a caller's inference tensor, which is re-validated on every call instead."""
+    t._dig_t_ok = (_tver(t), num_timesteps)
     return t
 
 
@@ -422,12 +441,13 @@ def _check_t(t, num_timesteps, B):
     dig_amd.guidance marks the tensors it builds from Python ints."""
     if t.dim() != 1 or t.shape[0] != B:
         raise ValueError(f"t must have shape [{B}], got {tuple(t.shape)}")
-    if not B or getattr(t, "_dig_t_ok", None) == (t._version, num_timesteps):
+    if not B or getattr(t, "_dig_t_ok", None) == (_tver(t), num_timesteps):
         return
     lo, hi = (int(v) for v in torch.aminmax(t))
     if lo < 0 or hi >= num_timesteps:
         raise IndexError(f"timestep out of range: t must lie in [0, {num_timesteps}), got [{lo}, {hi}]")
-    _mark_t_checked(t, num_timesteps)
+    if not t.is_inference():  # an inference tensor can be rewritten in place without a trace: never cache its validation
+        _mark_t_checked(t, num_timesteps)
 
 
 def _unet_forward(u, img, noise, t, sqrt_ac, sqrt_1mac, pre_scale, pre_shift, want_xt, debug=None, want_pred=True):
@@ -498,9 +518,15 @@ def _unet_forward(u, img, noise, t, sqrt_ac, sqrt_1mac, pre_scale, pre_shift, wa
         coff += chans[j + 1]
     pred = None
     if want_pred:
-        x = _resnet(P["final_rb"], x, r, ss)
         pred = torch.empty(B, u.out_dim, H, W, dtype=torch.float32, device=dev)
-        ops.gemm_nt(x, P["final_w"], pred, B * H * W, u.out_dim, u.dim, dtype=dt, bias=P["final_b"], out_f32=True, nchw_hw=H * W)
+        fr = P["final_rb"]
+        if fr["res"] is not None and ops.res_tail_final_supported(x, r, fr["res"][0].shape[0], H * W, u.out_dim):
+            # final_conv applied inside the tail kernel of final_res_block: the block's output never goes to HBM
+            _resnet(fr, x, r, ss, final=(P["final_w32"], P["final_b"], pred))
+        else:
+            x = _resnet(fr, x, r, ss)
+            keep("final_res_block", x)
+            ops.gemm_nt(x, P["final_w"], pred, B * H * W, u.out_dim, u.dim, dtype=dt, bias=P["final_b"], out_f32=True, nchw_hw=H * W)
     feats, o = [], 0
     for c in chans:
         feats.append(maps[:, o:o + c])

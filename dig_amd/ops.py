@@ -130,13 +130,31 @@ def linear_rows(x, w, bias=None, res=None, gelu=False, out_f32=False, x1=None, g
     return y
 
 
-def res_tail(x0, w, bias, x1, gsrc, gaff, rows_per_img):
+def res_tail_final_supported(x0, x1, N, rows_per_img, n_out):
+    """Whether res_tail can apply the Unet's final 1x1 conv to the block output in the same kernel (dig_pw_res, fout)."""
+    K0 = x0.shape[-1]
+    K1 = x1.shape[-1] if x1 is not None else 0
+    M = x0.numel() // K0
+    return (M % 32 == 0 and rows_per_img % 32 == 0 and K0 + K1 == 128 and N == 64 and 1 <= n_out <= 4
+            and bool(_lib.lib().dig_pw_res_supported(K0, K1, N, dtype_code(x0.dtype))))
+
+
+def res_tail(x0, w, bias, x1, gsrc, gaff, rows_per_img, final=None):
     """ResnetBlock tail with a channel-changing shortcut: res_conv([x0 | x1]) + SiLU(GroupNorm-apply(gsrc)).
-    Streaming kernel where the shape is supported (small K, N), otherwise the general GEMM with the same epilogue."""
+    Streaming kernel where the shape is supported (small K, N), otherwise the general GEMM with the same epilogue.
+    final = (fw [n_out, N] fp32, fb [n_out] fp32, pred [B, n_out, H, W] fp32): the block is the Unet's final_res_block and
+    final_conv is applied in the same kernel (caller checks res_tail_final_supported); the block output is then never stored
+    and None is returned."""
     K0 = x0.shape[-1]
     K1 = x1.shape[-1] if x1 is not None else 0
     N = w.shape[0]
     M = x0.numel() // K0
+    if final is not None:
+        fw, fb, pred = final
+        call("pw_res", x0=_chk(x0), x1=_chk(x1) if x1 is not None else None, w=_chk(w), bias=bias, gsrc=_chk(gsrc), gaff=gaff,
+             out=None, M=M, K0=K0, K1=K1, N=N, rows_per_img=rows_per_img, dtype=dtype_code(x0.dtype),
+             fw=_chk(fw), fb=_chk(fb), fout=_chk(pred), f_no=fw.shape[0])
+        return None
     if M % 32 == 0 and rows_per_img % 32 == 0 and _lib.lib().dig_pw_res_supported(K0, K1, N, dtype_code(x0.dtype)):
         out = torch.empty(*x0.shape[:-1], N, dtype=x0.dtype, device=x0.device)
         call("pw_res", x0=_chk(x0), x1=_chk(x1) if x1 is not None else None, w=_chk(w), bias=bias, gsrc=_chk(gsrc), gaff=gaff,

@@ -130,6 +130,13 @@ typedef struct {
     void* out;
     long long M;
     int K0, K1, N, rows_per_img, dtype;
+    /* Optional fused final_conv (ddp.py:373,443-448; K0+K1 = 128, N = 64 only): when fout != NULL the block output is not
+     * stored (out may be NULL); instead fout[img][o][pixel] = fb[o] + sum_c fw[o][c] * result[pixel][c] in fp32, NCHW,
+     * o < f_no <= 4, pixel < rows_per_img. */
+    const float* fw;
+    const float* fb;
+    float* fout;
+    int f_no;
 } dig_pw_res_args;
 int dig_pw_res_supported(int K0, int K1, int N, int dtype);
 int dig_pw_res(const dig_pw_res_args* a, void* stream);
@@ -214,7 +221,8 @@ int dig_la_finalize(const dig_la_finalize_args* a, void* stream);
  *                 1/||x|| as a row scale), online softmax of k over pixels, ctxT[e][d] += v^T exp(k - m) with both MFMA
  *                 operands taken from the accumulators.  wkv: [256][C] = (k rows | v rows) * g.  Outputs per
  *                 (b, split, head): part [32 e][32 d] fp32, pmax[32 d], psum[32 d].  Needs 4 heads of 32, C in {16..256}.
- *   dig_la_merge: log-sum-exp merge of the splits -> ctx[b][h][d][e] in dtype (B operand of the M_b GEMM).
+ *   dig_la_merge: log-sum-exp merge of the splits -> ctx[b][h][d][e] in dtype (B operand of the M_b GEMM), and optionally
+ *                 M_b itself (second einsum folded into to_out, ddp.py:231-232) in the same launch.
  *   dig_la_out  : q = softmax_d(W'q x) * scale, y = M_b q + bias, out = RMSNorm(y) * g2 + x.   mb: [B][dim][128]. */
 typedef struct {
     const void* x;
@@ -231,6 +239,11 @@ typedef struct {
     const float* psum;
     void* ctx;
     int B, splits, dtype;
+    /* Optional (mb != NULL): also form M_b[b][c][h*32+d] = sum_e wo[c][h*32+e] * ctx[b][h][d][e] in the same launch
+     * (wo: to_out weight [dim][128] in dtype, mb: [B][dim][128] in dtype); ctx may then be NULL. */
+    const void* wo;
+    void* mb;
+    int dim;
 } dig_la_merge_args;
 int dig_la_merge(const dig_la_merge_args* a, void* stream);
 typedef struct {
@@ -391,6 +404,32 @@ typedef struct {
     int B, dim, dtype;
 } dig_sinusoid_args;
 int dig_sinusoid(const dig_sinusoid_args* a, void* stream);
+
+/* Time embedding head in one launch: SinusoidalPosEmb(dim) -> Linear(dim, tdim) -> GELU(erf) -> Linear(tdim, tdim)
+ * (ddp.py:118-130,316-321; Unet.forward ddp.py:391), fp32.  temb [B][tdim] = the embedding, st [B][tdim] = SiLU(temb)
+ * (first half of every ResnetBlock's `mlp`, ddp.py:172-173).  w1 [tdim][dim], w3 [tdim][tdim] row-major. */
+typedef struct {
+    const long long* t;
+    const float* w1;
+    const float* b1;
+    const float* w3;
+    const float* b3;
+    float* temb;
+    float* st;
+    int B, dim, tdim;
+} dig_time_embed_args;
+int dig_time_embed(const dig_time_embed_args* a, void* stream);
+
+/* Every ResnetBlock's Linear(tdim, 2*C_out) (ddp.py:174,186-188) as one skinny fp32 GEMM: out[b][n] = bias[n] + st[b][:] . w[n][:],
+ * st [B][K], w [N][K] (the 19 projections concatenated along N), out [B][N]; exact fp32 MFMA. */
+typedef struct {
+    const float* st;
+    const float* w;
+    const float* bias;
+    float* out;
+    int B, N, K;
+} dig_time_mlp_args;
+int dig_time_mlp(const dig_time_mlp_args* a, void* stream);
 
 /* elementwise activation on a flat buffer: act 0 = SiLU (ddp.py:173), 1 = GELU(erf) (ddp.py:319) */
 typedef struct {

@@ -401,6 +401,17 @@ def test_pw_res_tail(shape):
     assert (y.float().cpu() - ref).abs().max() <= tol(dt, ref)
     y2 = ops.linear_rows(d(x0), d(w), bias=bias.to(DEV), x1=d(x1), gsrc=d(h2), gaff=aff.to(DEV), rows_per_img=H * W)
     assert (y.float() - y2.float()).abs().max().item() <= tol(dt, ref)
+    if K0 + K1 == 128 and N == 64:
+        # the Unet's final_conv (ddp.py:373,443-448) fused into the tail: fp32 NCHW result of conv1x1(N -> n_out) on the fp32
+        # block output, which is never stored
+        for n_out in (3, 1, 4):
+            fw, fb = rnd("pwfw", (n_out, N), N ** -0.5), rnd("pwfb", (n_out,), 0.1)
+            assert ops.res_tail_final_supported(d(x0), d(x1), N, H * W, n_out)
+            pred = torch.full((B, n_out, H, W), float("nan"), device=DEV)
+            r = ops.res_tail(d(x0), d(w), bias.to(DEV), d(x1), d(h2), aff.to(DEV), H * W, final=(fw.to(DEV), fb.to(DEV), pred))
+            assert r is None
+            fref = (ref @ fw.t() + fb).permute(0, 3, 1, 2)
+            assert (pred.cpu() - fref).abs().max() <= 1e-4 * max(1.0, float(fref.abs().max()))
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -582,3 +593,48 @@ def test_gemm_random_shapes():
         dev = lambda t: t.to(device=DEV, dtype=dt)
         y = ops.linear_rows(dev(x0), dev(w), bias=b.to(DEV), x1=dev(x1) if K1 else None, res=dev(res) if res is not None else None, gelu=gelu)
         assert (y.float().cpu() - ref).abs().max() <= tol(dt, ref), (it, dt, M, N, K0, K1)
+
+
+@pytest.mark.parametrize("B", [1, 5, 32, 70])
+def test_time_embedding_fused(B):
+    """dig_time_embed + dig_time_mlp (sinusoid -> Linear -> GELU -> Linear, SiLU, all block projections) vs plain torch fp32
+    (ddp.py:118-130,316-321,172-175)."""
+    dim, tdim, N = 64, 256, 8064 if B == 32 else 200
+    t = torch.tensor([(37 * i + 100) % 1000 for i in range(B)], dtype=torch.long)
+    w1, b1 = rnd("te.w1", (tdim, dim), dim ** -0.5), rnd("te.b1", (tdim,), 0.1)
+    w3, b3 = rnd("te.w3", (tdim, tdim), tdim ** -0.5), rnd("te.b3", (tdim,), 0.1)
+    wm, bm = rnd("te.wm", (N, tdim), tdim ** -0.5), rnd("te.bm", (N,), 0.1)
+    temb_ref = O.time_embedding({"1.weight": w1, "1.bias": b1, "3.weight": w3, "3.bias": b3}, t, dim)
+    ss_ref = F.linear(F.silu(temb_ref), wm, bm)
+    d = lambda x: x.to(DEV).contiguous()
+    temb, st = torch.empty(B, tdim, device=DEV), torch.empty(B, tdim, device=DEV)
+    call("time_embed", t=d(t), w1=d(w1), b1=d(b1), w3=d(w3), b3=d(b3), temb=temb, st=st, B=B, dim=dim, tdim=tdim)
+    ss = torch.full((B, N), float("nan"), device=DEV)
+    call("time_mlp", st=st, w=d(wm), bias=d(bm), out=ss, B=B, N=N, K=tdim)
+    assert (temb.cpu() - temb_ref).abs().max() <= 2e-5
+    assert (st.cpu() - F.silu(temb_ref)).abs().max() <= 2e-5
+    assert (ss.cpu() - ss_ref).abs().max() <= 5e-5
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cfg", [(3, 64, 16), (2, 128, 1), (1, 256, 32), (2, 16, 5)])
+def test_la_merge_with_mb(dt, cfg):
+    """dig_la_merge with the fused M_b output vs the stand-alone merge followed by the batched GEMM it replaces
+    (M_b[c][h*32+d] = sum_e Wout[c][h*32+e] ctx[h][d][e], ddp.py:231-232): identical context, M_b equal up to the storage
+    rounding of a different fp32 summation order."""
+    B, dim, splits = cfg
+    part = rnd("mm.part", (B, splits, 4, 32, 32)).to(DEV)
+    pmax = rnd("mm.pmax", (B, splits, 4, 32), 3.0).to(DEV)
+    psum = (rnd("mm.psum", (B, splits, 4, 32)).abs() + 0.5).to(DEV)
+    wo = q(rnd("mm.wo", (dim, 128), 128 ** -0.5), dt).to(device=DEV, dtype=dt)
+    ctx = torch.empty(B * 4, 32, 32, dtype=dt, device=DEV)
+    call("la_merge", part=part, pmax=pmax, psum=psum, ctx=ctx, B=B, splits=splits, dtype=dtype_code(dt))
+    mb_ref = torch.einsum("che,bhde->bchd", wo.float().reshape(dim, 4, 32), ctx.float().reshape(B, 4, 32, 32)).reshape(B, dim, 128)
+    ctx2 = torch.empty_like(ctx)
+    mb = torch.full((B, dim, 128), float("nan"), dtype=dt, device=DEV)
+    call("la_merge", part=part, pmax=pmax, psum=psum, ctx=ctx2, B=B, splits=splits, dtype=dtype_code(dt), wo=wo, mb=mb, dim=dim)
+    assert torch.equal(ctx, ctx2)
+    assert (mb.float() - mb_ref).abs().max().item() <= (1e-5 if dt == torch.float32 else 2.0 ** -8) * max(1.0, float(mb_ref.abs().max()))
+    mb3 = torch.empty_like(mb)
+    call("la_merge", part=part, pmax=pmax, psum=psum, ctx=None, B=B, splits=splits, dtype=dtype_code(dt), wo=wo, mb=mb3, dim=dim)
+    assert torch.equal(mb, mb3)
