@@ -13,9 +13,8 @@
 namespace {
 
 // FIN: the block is the Unet's final_res_block and the 1x1 final_conv (ddp.py:373,443-448: N -> f_no <= 4 channels, fp32 NCHW) is
-// applied to the fp32 result while it is still in the accumulator layout: the block's output never goes to HBM (at 256x256 a
-// 268 MB write + read and one launch).  Lane (pixel r, half hf) owns 32 of the pixel's 64 channels; one xor-32 shuffle
-// completes the dot products.
+// applied to the block output while its rows sit in the wave's LDS tile: the output never goes to HBM (at 256x256 a 268 MB
+// write + read and one launch).
 template <int KS, int NT, bool FIN>
 __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void pw_res_kernel(dig_pw_res_args a, int iters) {
     constexpr int K = KS * 16, N = NT * 32, KP = K + 8, NP = N + 8;
@@ -51,8 +50,9 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void pw_res_kernel(dig_pw_r
     const long long nsub = a.M / 32;
     const long long sub0 = ((long long)blockIdx.x * iters) * 4 + wave;
 
-    bf16x8 px[NVX], pg[NVG];
-    auto gload = [&](long long sub) {
+    // register sets of the prefetch (PD2: two sub-tiles ahead instead of one)
+    bf16x8 pxa[NVX], pga[NVG], pxb[NVX], pgb[NVG];
+    auto gload = [&](long long sub, bf16x8(&px)[NVX], bf16x8(&pg)[NVG]) {
         const long long row0 = sub * 32;
 #pragma unroll
         for (int i = 0; i < NVX; i++) {
@@ -68,11 +68,14 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void pw_res_kernel(dig_pw_r
         }
     };
     int cur_img = -1;
-    if (sub0 < nsub) gload(sub0);
-    for (int it = 0; it < iters; it++) {
+    if (sub0 < nsub) gload(sub0, pxa, pga);
+    constexpr bool PD2 = false;  // measured (B = 32, 256x256): a second set in flight changes nothing at N = 64 (219 vs 216 us) and costs 12 % at K = 192 - the
+                                 // kernel is not latency bound; the single-set loop is kept
+    if (PD2 && iters > 1 && sub0 + 4 < nsub) gload(sub0 + 4, pxb, pgb);
+    auto step = [&](int it, bf16x8(&px)[NVX], bf16x8(&pg)[NVG]) {
         const long long sub = sub0 + (long long)it * 4;
-        if (sub >= nsub) break;
-        const int img = (int)((sub * 32) / a.rows_per_img);
+        if (it >= iters || sub >= nsub) return;
+        const int img = ((int)sub * 32) / a.rows_per_img;
         __builtin_amdgcn_wave_barrier();
         if (img != cur_img) {  // wave-uniform: refresh this wave's GroupNorm affine table
             for (int i = lane; i < N * 2 / 4; i += 64)
@@ -92,8 +95,18 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void pw_res_kernel(dig_pw_r
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (it + 1 < iters && sub + 4 < nsub) gload(sub + 4);
+        if constexpr (PD2) {
+            if (it + 2 < iters && sub + 8 < nsub) gload(sub + 8, px, pg);
+        } else {
+            if (it + 1 < iters && sub + 4 < nsub) gload(sub + 4, px, pg);
+        }
 
+        const bf16* wsp = ws;
+        if constexpr (FIN) {  // keep the 64 registers of weight fragments from being hoisted out of the loop (FIN has none to spare)
+            int opq = 0;
+            asm volatile("" : "+s"(opq));
+            wsp = ws + opq;
+        }
         f32x16 acc[NT];
 #pragma unroll
         for (int ct = 0; ct < NT; ct++)
@@ -110,12 +123,11 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void pw_res_kernel(dig_pw_r
 #pragma unroll
             for (int ct = 0; ct < NT; ct++) {
                 Frag<bf16> fa;
-                frag_load<bf16>(fa, ws + (ct * 32 + r) * KP + ks * 16 + hf * 8);
+                frag_load<bf16>(fa, wsp + (ct * 32 + r) * KP + ks * 16 + hf * 8);
                 mma16<bf16>(acc[ct], fa, fb);
             }
         }
         // + SiLU(a h2 + b), in place over the h2 rows (pixel r of this lane, channels ct*32 + 8 q4 + 4 hf + 0..3)
-        float fd[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ct = 0; ct < NT; ct++)
 #pragma unroll
@@ -128,30 +140,44 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void pw_res_kernel(dig_pw_r
                 const float v1 = acc[ct][4 * q4 + 1] + silu_f(ab0[2] * (float)g[1] + ab0[3]);
                 const float v2 = acc[ct][4 * q4 + 2] + silu_f(ab1[0] * (float)g[2] + ab1[1]);
                 const float v3 = acc[ct][4 * q4 + 3] + silu_f(ab1[2] * (float)g[3] + ab1[3]);
-                if constexpr (FIN) {
-                    const float v[4] = {v0, v1, v2, v3};
+                *reinterpret_cast<bf16x4*>(gp) = bf16x4{(bf16)v0, (bf16)v1, (bf16)v2, (bf16)v3};
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if constexpr (FIN) {
+            // final_conv on the block output as stored (bf16 rows in LDS, the accumulators are dead by now): lane (pixel r, half hf)
+            // takes channels hf*N/2 .. +N/2-1, one xor-32 shuffle completes the dot products; fout[img][o][pixel], lanes of half hf
+            // store planes o = hf and hf + 2 (32 consecutive pixels = 128 bytes each)
+            float fd[4] = {0.f, 0.f, 0.f, 0.f};
+            // (an opaque zero ties the weight reads to the iteration: left loop-invariant, all 128 of them are hoisted into
+            // registers and the kernel spills)
+            int opq = 0;
+            asm volatile("" : "+s"(opq));
+            const float* fwp = fw_l + opq;
 #pragma unroll
-                    for (int o = 0; o < 4; o++) {
-                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(fw_l + o * N + c0);
+            for (int v8 = 0; v8 < N / 16; v8++) {
+                const int c0 = hf * (N / 2) + v8 * 8;
+                const bf16x8 g = *reinterpret_cast<const bf16x8*>(gs + r * NP + c0);
 #pragma unroll
-                        for (int j = 0; j < 4; j++) fd[o] += w4[j] * v[j];
-                    }
-                } else {
-                    *reinterpret_cast<bf16x4*>(gp) = bf16x4{(bf16)v0, (bf16)v1, (bf16)v2, (bf16)v3};
+                for (int o = 0; o < 4; o++) {
+                    const f32x4 wa = *reinterpret_cast<const f32x4*>(fwp + o * N + c0), wb = *reinterpret_cast<const f32x4*>(fwp + o * N + c0 + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) fd[o] = fmaf(wa[j], (float)g[j], fd[o]);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) fd[o] = fmaf(wb[j], (float)g[4 + j], fd[o]);
                 }
             }
-        if constexpr (FIN) {
-            // fout[img][o][pixel]: lanes of half hf store planes o = hf and hf + 2 (32 consecutive pixels = 128 bytes each)
-            const long long row = sub * 32 + r;
-            const long long im = row / a.rows_per_img, pix = row - im * a.rows_per_img;
+            const int row = (int)sub * 32 + r;  // M < 2^31 (checked on the host)
+            const int im = row / a.rows_per_img, pix = row - im * a.rows_per_img;
 #pragma unroll
             for (int o = 0; o < 4; o++) fd[o] += __shfl_xor(fd[o], 32, 64);
 #pragma unroll
             for (int oo = 0; oo < 2; oo++) {
                 const int o = hf + 2 * oo;
-                if (o < a.f_no) a.fout[(im * a.f_no + o) * a.rows_per_img + pix] = (hf ? fd[1 + 2 * oo] : fd[2 * oo]) + a.fb[o];
+                if (o < a.f_no) a.fout[((size_t)im * a.f_no + o) * a.rows_per_img + pix] = (hf ? fd[1 + 2 * oo] : fd[2 * oo]) + a.fb[o];
             }
-            continue;
+            return;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -161,6 +187,14 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void pw_res_kernel(dig_pw_r
             const int idx = lane + i * 64, row = idx / (N / 8), v = idx - row * (N / 8);
             *reinterpret_cast<bf16x8*>(out + (size_t)(sub * 32 + row) * N + v * 8) = *reinterpret_cast<const bf16x8*>(gs + row * NP + v * 8);
         }
+    };
+    if constexpr (PD2) {
+        for (int it = 0; it < iters; it += 2) {
+            step(it, pxa, pga);
+            step(it + 1, pxb, pgb);
+        }
+    } else {
+        for (int it = 0; it < iters; it++) step(it, pxa, pga);
     }
 }
 
@@ -208,7 +242,7 @@ extern "C" int dig_pw_res(const dig_pw_res_args* a, void* stream_) {
     }
     DIG_CHECK(a->K1 == 0 || a->x1, DIG_EINVAL, "pw_res: K1 > 0 needs x1");
     DIG_CHECK(dig_pw_res_supported(a->K0, a->K1, a->N, a->dtype), DIG_EINVAL, "pw_res: unsupported shape K0=%d K1=%d N=%d dtype=%d", a->K0, a->K1, a->N, a->dtype);
-    DIG_CHECK(a->M > 0 && a->M % 32 == 0 && a->rows_per_img > 0 && a->rows_per_img % 32 == 0, DIG_EINVAL, "pw_res: M and rows_per_img must be multiples of 32");
+    DIG_CHECK(a->M > 0 && a->M < (1ll << 31) && a->M % 32 == 0 && a->rows_per_img > 0 && a->rows_per_img % 32 == 0, DIG_EINVAL, "pw_res: M and rows_per_img must be multiples of 32");
     DIG_CHECK(((uintptr_t)a->x0 | (uintptr_t)a->x1 | (uintptr_t)a->w | (uintptr_t)a->gsrc | (uintptr_t)a->gaff | (uintptr_t)a->out) % 16 == 0, DIG_EALIGN,
               "pw_res: pointers must be 16-byte aligned");
     if (a->fout) return launch<8, 2, true>(a, st);

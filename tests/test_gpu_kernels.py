@@ -402,8 +402,8 @@ def test_pw_res_tail(shape):
     y2 = ops.linear_rows(d(x0), d(w), bias=bias.to(DEV), x1=d(x1), gsrc=d(h2), gaff=aff.to(DEV), rows_per_img=H * W)
     assert (y.float() - y2.float()).abs().max().item() <= tol(dt, ref)
     if K0 + K1 == 128 and N == 64:
-        # the Unet's final_conv (ddp.py:373,443-448) fused into the tail: fp32 NCHW result of conv1x1(N -> n_out) on the fp32
-        # block output, which is never stored
+        # the Unet's final_conv (ddp.py:373,443-448) fused into the tail: fp32 NCHW result of conv1x1(N -> n_out) on the block
+        # output, which is never stored
         for n_out in (3, 1, 4):
             fw, fb = rnd("pwfw", (n_out, N), N ** -0.5), rnd("pwfb", (n_out,), 0.1)
             assert ops.res_tail_final_supported(d(x0), d(x1), N, H * W, n_out)
@@ -411,7 +411,10 @@ def test_pw_res_tail(shape):
             r = ops.res_tail(d(x0), d(w), bias.to(DEV), d(x1), d(h2), aff.to(DEV), H * W, final=(fw.to(DEV), fb.to(DEV), pred))
             assert r is None
             fref = (ref @ fw.t() + fb).permute(0, 3, 1, 2)
-            assert (pred.cpu() - fref).abs().max() <= 1e-4 * max(1.0, float(fref.abs().max()))
+            # (the conv is applied to the block output as the unfused path stores it, i.e. rounded to bf16)
+            assert (pred.cpu() - fref).abs().max() <= 5e-3 * max(1.0, float(fref.abs().max()))
+            fref_b = (ref.to(dt).float() @ fw.t() + fb).permute(0, 3, 1, 2)
+            assert (pred.cpu() - fref_b).abs().mean() <= 2e-4 * max(1.0, float(fref.abs().max()))
 
 
 @pytest.mark.parametrize("dt", DTYPES)
