@@ -378,7 +378,7 @@ extern "C" int dig_conv3x3_tiles(int H, int W, int C0, int C1, int Cout, int gro
 }
 
 extern "C" int dig_conv3x3_wlayout(int C0, int C1, int Cout, int dtype) {
-    return conv3x3_db_eligible(C0, C1, Cout, dtype) ? 1 : 0;
+    return conv3x3_db_eligible(C0, C1, Cout, dtype) ? 2 : 0;
 }
 
 extern "C" int dig_conv3x3_config(int Cout, int dtype, int* BN, int* KC) {

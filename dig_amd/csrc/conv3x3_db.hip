@@ -1,17 +1,30 @@
-// conv3x3 (pad 1) for the wide layers (Cout % 128 == 0, bf16): double-buffered implicit GEMM, gfx950.
+// conv3x3 (pad 1) for the wide layers (Cout % 128 == 0, bf16): double-buffered implicit GEMM on v_mfma_f32_16x16x32_bf16, gfx950.
 //
-// Same tiling idea as conv3x3.hip (one 18x18 halo tile of KC = 16 input channels serves all 9 taps), rebuilt around the
-// data movement that bounds those layers: a 16x16-pixel x 128-channel tile re-reads its whole [9][128][Cin] weight
-// panel from L2, 36 KB per 16-channel chunk.
-//   * 32x16-pixel x 128-channel tile per block, so a weight chunk is shared by twice as many MFMAs;
-//   * 512 threads = 8 waves (8 pixel groups of 4 rows, 64 px x 128 ch each), ONE block per CU;
-//   * two LDS buffers of {halo chunk, weight chunk}; the weight chunk of step c+1 goes global -> LDS directly
-//     (global_load_lds_dwordx4, no registers, no LDS store instructions) while step c is multiplied; the halo chunk
-//     still passes through registers (concat / nearest-x2 / GroupNorm-apply + SiLU prologue happen there);
-//   * one barrier per chunk.
-// The weight slabs are packed on the host exactly as they sit in LDS: [n_tile][chunk][9][128][16] with the two 16-byte
-// halves of a row swapped when bit 3 of the row index is set - with that, unpadded 32-byte rows are read
-// conflict-free by ds_read_b128 (dig_conv3x3_wlayout reports the layout to the packer).
+// Tiling as conv3x3.hip (one halo tile of KC = 16 input channels serves all 9 taps), rebuilt around the data movement and
+// the clock that bound those layers:
+//   * 32x16-pixel x 128-channel tile per block, 512 threads = 8 waves (8 pixel groups of 4 rows: 64 px x 128 ch each,
+//     32 accumulator tiles of 16x16), ONE block per CU; a 16-row / 4-wave variant for launches that would leave CUs idle;
+//   * the matrix instruction is the 16x16x32 form: on this part a loop of them holds a 12-14 % higher clock than the same
+//     flops issued as 32x32x16 (MI355X_MICROARCH.md, DVFS give-back item 7; tools/lab/mfma_peak: 2.15 vs 1.88 PFLOP/s),
+//     with the same LDS fragment traffic for the same 64 x 128 register tile (12 ds_read_b128 per 32 MFMAs);
+//   * K = 32 of one instruction = TWO TAPS x 16 channels: taps (0,1), (2,3), (4,5), (6,7) of a chunk are four K steps, and
+//     tap 8 is paired ACROSS chunks - tap 8 of chunks 2P and 2P+1 form one K step, issued in the odd period.  For that the
+//     halo is a ring of THREE chunk buffers (chunk 2P is still resident in period 2P+1) and the tap-8 weights of a chunk
+//     pair are a slab of their own;
+//   * weights are the A operand (accumulator rows = channels): a lane ends up with 8 consecutive output channels of one
+//     pixel (two row-permuted 16-channel tiles), so the epilogue converts to bf16 in registers and passes 16-byte vectors
+//     through the wave's own LDS rows - no fp32 staging, no epilogue barriers except the one of the GroupNorm statistics;
+//   * everything goes global -> LDS by LDS-DMA (global_load_lds_dwordx4, no registers, no LDS store instructions): the weight
+//     slabs and the halo chunk (concat / nearest-x2 are source addressing).  A GroupNorm-apply + SiLU prologue (PRO) is applied
+//     IN PLACE in LDS: each lane transforms exactly the 16-byte slots its own DMA instructions wrote (so its own vmcnt tells
+//     it they have landed), inside the MFMA sequence of the period before the chunk is used; one barrier per chunk.
+// Weight slabs are packed on the host exactly as they sit in LDS (dig_conv3x3_wlayout == 2, see ops.ConvWeight):
+//   per 128-channel N tile, per chunk pair P:  main(2P) | main(2P+1) | w8(P)
+//   main(c): [4 K steps][128 rows][4 slots x 16 B]  slot s of K step p = tap 2p + (s >> 1), channel half s & 1 of chunk c
+//   w8(P)  : [128 rows][4 slots x 16 B]             slot s = tap 8 of chunk 2P + (s >> 1), channel half s & 1
+//   row rho = mt*16 + rr holds output channel 32*(mt >> 1) + 8*(rr >> 2) + 4*(mt & 1) + (rr & 3) of the N tile, and its
+//   four 16-byte slots are stored at position s ^ f[(rho >> 2) & 3], f = {0, 2, 3, 1}: with 64-byte rows that makes the
+//   16-lane groups of ds_read_b128 hit 16 different 16-byte bank groups (MI355X_MICROARCH.md, LDS).
 #include <cstdlib>
 
 #include "common.hpp"
@@ -22,46 +35,27 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int BN = 128, KC = 16, HALO_W = 18;
+constexpr int WMAIN_BYTES = 4 * BN * 64;                // 32768: taps 0..7 of one chunk = 4 K steps
+constexpr int W8_BYTES = BN * 64;                       // 8192: tap 8 of a chunk pair = 1 K step
+constexpr int PAIR_BYTES = 2 * WMAIN_BYTES + W8_BYTES;  // 73728 = 2 chunks x 9 taps x 128 x 16 x 2 B
+
 // NW = waves per block = 4-row pixel groups per tile: 8 (32x16-pixel tile, the default) or 4 (16x16-pixel tile, for launches
-// whose 32-row tiles would leave CUs idle: e.g. 256->256 at 32x32 with B = 32 is 128 blocks of 8 waves or 256 of 4)
-constexpr int BN = 128, KC = 16, KCP = KC + 8, HALO_W = 18;
-constexpr int HROW = 512;                               // halo row stride in elements (18 * 24 * 2 B = 864 -> 1024 B)
-constexpr int WSLAB_BYTES = 9 * BN * KC * 2;            // 36864
-constexpr int NH = 3;                                   // halo vectors per thread per chunk (NW=8: 34*18*2 = 1224 of 1536 slots; NW=4: 648 of 768)
-constexpr int OS = BN + 4;                              // fp32 staging row stride of the epilogue
-// DMAH: the halo chunk too goes global -> LDS by LDS-DMA (launches without a GroupNorm/SiLU prologue: nothing has to pass
-// through registers).  Its LDS image is the plain [halo pixel][16 channels] array (32 B per pixel, no row padding); a DMA
-// instruction writes 64 consecutive 16-byte slots, so the bank swizzle is applied on the SOURCE side: slot (pixel, h) holds
-// channel half h ^ (halo row & 1).  A ds_read_b128 is served in four 16-lane groups that mix two fragment rows ({0-3, 12-15,
-// 20-27}, ...: MI355X_MICROARCH.md, LDS): within a row the 8 lanes of a group hit 8 different 32-byte pixels (18 pixels per
-// row = 2 mod 8 of them), and the lane of the other row that lands on the same 32 bytes reads the other half - all 64 banks.
-// (A swizzle by bit 3 of the column, right for 32-lane groups, left 5 % of the kernel's cycles in bank conflicts.)  Out-of-image
-// pixels are zeroed once (both buffers) and their lanes masked out of every DMA.
-template <int NW, bool DMAH = false> struct DbCfg {
+// whose 32-row tiles would leave CUs idle: e.g. 256->256 at 32x32 with B = 32 is 128 blocks of 8 waves or 256 of 4).
+// The halo LDS image is the plain [halo pixel][16 channels] array (32 B per pixel, no padding); a DMA instruction writes 64
+// consecutive 16-byte slots, so the bank swizzle is applied on the SOURCE side: slot (pixel, h) holds channel half
+// h ^ (halo row & 1).  A fragment is 16 pixels of ONE row x 2 halves x 2 taps; the 16 lanes that ds_read_b128 serves together
+// read 8 consecutive pixels' one half and the other 8 pixels' other half: all 64 banks.
+template <int NW> struct DbCfg {
     static constexpr int TILE_H = 4 * NW, HALO_H = TILE_H + 2, NTHREADS = 64 * NW;
-    static constexpr int HSLOTS = HALO_H * HALO_W * 2, HPIECES = (HSLOTS + 63) / 64;                 // 16-byte slots, 1 KB DMA pieces
-    static constexpr int HALO_BYTES = DMAH ? HPIECES * 1024 : HALO_H * HROW * 2;                     // NW=8: 20480 / 34816
-    static constexpr int BUF_BYTES = HALO_BYTES + WSLAB_BYTES;     // NW=8: 71680
-    static constexpr int EPI_BYTES = NW * 32 * (BN + 4) * 4;       // fp32 staging of one output half in the epilogue (NW=8: 135168)
-    static constexpr int DB_LDS = 2 * BUF_BYTES > EPI_BYTES ? 2 * BUF_BYTES : EPI_BYTES;  // NW=8: 143360 (135168 with DMAH), NW=4: 110592 / 96256
+    static constexpr int HSLOTS = HALO_H * HALO_W * 2, HPIECES = (HSLOTS + 63) / 64;  // 16-byte slots, 1 KB DMA pieces
+    static constexpr int HALO_BYTES = HPIECES * 1024;                                 // NW=8: 20480, NW=4: 11264
+    static constexpr int W_OFF = 3 * HALO_BYTES;                                      // ring of three halo chunks, then the weights
+    static constexpr int AFF_OFF = W_OFF + 2 * WMAIN_BYTES + 2 * W8_BYTES;            // NW=8: 143360, NW=4: 115712
+    static constexpr int AFF_MAX_C = 2048;                                            // PRO: [C0][2] fp32 GroupNorm affine of this image
+    static constexpr int DB_LDS = AFF_OFF;
+    static constexpr int DB_LDS_PRO = AFF_OFF + AFF_MAX_C * 8;                        // NW=8: 159744 of 163840
 };
-
-#ifndef DB_TAP_ISSUE
-#define DB_TAP_ISSUE 0
-#endif
-#ifndef DB_TAP_STORE_A
-#define DB_TAP_STORE_A 7
-#endif
-#ifndef DB_TAP_STORE_B
-#define DB_TAP_STORE_B 5
-#endif
-
-#ifdef DB_TRACE
-__device__ unsigned long long db_trace[8 * 64 * 8];
-#define DB_STAMP(slot) db_t[slot] = __builtin_amdgcn_s_memtime();
-#else
-#define DB_STAMP(slot)
-#endif
 
 struct DbParams {
     const bf16* in[2];
@@ -75,87 +69,56 @@ struct DbParams {
     int B, H, W, Cout, groups, up2, tiles_x, tiles_y;
 };
 
-template <int NW, bool DMAH> __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(DbParams p) {
-    using Cfg = DbCfg<NW, DMAH>;
+// (PRO instantiations run without the fences: with the prologue's registers on top they spill, measured 8 % slower at 16-row tiles)
+#define DB_FENCE                                                  \
+    do {                                                          \
+        if constexpr (!PRO) __builtin_amdgcn_sched_barrier(0);    \
+    } while (0)
+__device__ __forceinline__ f32x4 mma32(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int NW, bool PRO> __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(DbParams p) {
+    using Cfg = DbCfg<NW>;
     constexpr int TILE_H = Cfg::TILE_H, HALO_H = Cfg::HALO_H, NTHREADS = Cfg::NTHREADS;
-    constexpr int HALO_BYTES = Cfg::HALO_BYTES, BUF_BYTES = Cfg::BUF_BYTES;
+    constexpr int HALO_BYTES = Cfg::HALO_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pg = wave;  // pixel group: tile rows 4pg..4pg+3; every wave computes all 128 channels
-    const int r = lane & 31, hf = lane >> 5;
+    const int col = lane & 15, g = lane >> 4;  // fragment row (weights) / pixel column; K group: 8 of the 32 K values
     const int tiles = p.tiles_x * p.tiles_y;
     const int b = blockIdx.x / tiles, tile = blockIdx.x % tiles;
     const int ty0 = (tile / p.tiles_x) * TILE_H, tx0 = (tile % p.tiles_x) * 16;
     const int n0 = blockIdx.y * BN;
     const int Hs = p.up2 ? p.H >> 1 : p.H, Ws = p.up2 ? p.W >> 1 : p.W;
     const int nch0 = p.C[0] / KC, nch1 = p.C[1] / KC, nch = nch0 + nch1;
-    const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w) + (size_t)blockIdx.y * nch * WSLAB_BYTES;
+    const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w) + (size_t)blockIdx.y * ((nch + 1) >> 1) * PAIR_BYTES;
 
-    f32x16 acc[2][4];
+    f32x4 acc[8][4];  // [channel tile mt][pixel row mr]
 #pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int e = 0; e < 16; e++) acc[i >> 2][i & 3][e] = 0.f;
+    for (int i = 0; i < 32; i++) acc[i >> 2][i & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- halo staging through registers.  Everything that does not depend on the chunk is computed once: the source
-    // pixel of each of the thread's two vectors (clamped into the image; out-of-image pixels are zeroed at the LDS
-    // store), its validity and its LDS offset.
-    const int c8 = tid & 1;
-    Frag<bf16> hreg[NH];
-    int spix[NH], loff[NH];
-    bool hval[NH];
+    // ---- fragment addresses (bytes).  Weights: row `col` of a 16-row tile, slot g swizzled (see the header).
+    const int woff = col * 64 + ((g ^ ((0x1320 >> (4 * (col >> 2))) & 3)) << 4);
+    // Pixels: K step q covers taps 2q and 2q+1; this lane's tap is 2q + (g >> 1), its channel half g & 1.  Halo row of pixel
+    // row mr = 4pg + mr + ky (4pg is even): even mr read from hbe[q] (+ 2 rows for mr = 2), odd mr from hbo[q].
+    // The odd-row address is the even-row one a halo row further with the slot bit flipped: (hbe + 576) ^ 16 (576 has no bits
+    // below bit 6, so the add cannot carry into bit 4) - formed at the use, which keeps five registers free.
+    int hbe[4];
 #pragma unroll
-    for (int i = 0; i < NH; i++) {
-        const int idx = tid + i * NTHREADS;
-        const int pix = min(idx >> 1, HALO_H * HALO_W - 1);
-        const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
-        const int Y = ty0 + hy - 1, X = tx0 + hx - 1;
-        hval[i] = Y >= 0 && Y < p.H && X >= 0 && X < p.W;
-        const int Yc = min(max(Y, 0), p.H - 1), Xc = min(max(X, 0), p.W - 1);
-        const int sy = p.up2 ? Yc >> 1 : Yc, sx = p.up2 ? Xc >> 1 : Xc;
-        spix[i] = sy * Ws + sx;
-        loff[i] = idx < HALO_H * HALO_W * 2 ? (hy * HROW + hx * KCP + c8 * 8) : -1;
+    for (int q = 0; q < 4; q++) {
+        const int tap = 2 * q + (g >> 1), ky = tap / 3, kx = tap - 3 * ky;
+        hbe[q] = ((4 * pg + ky) * HALO_W + col + kx) * 32 + (((g & 1) ^ (ky & 1)) << 4);
     }
-    auto gload = [&](int ci) {
-        const int piece = ci >= nch0 ? 1 : 0;
-        const int cb = (ci - (piece ? nch0 : 0)) * KC;
-        const int Cp = p.C[piece];
-        const bf16* src = p.in[piece] + (size_t)b * (piece ? (size_t)Hs * Ws * Cp : (size_t)p.bstride0) + cb + c8 * 8;
-#pragma unroll
-        for (int i = 0; i < NH; i++) frag_load<bf16>(hreg[i], src + (size_t)spix[i] * Cp);
-    };
-    auto lstore = [&](int ci, unsigned char* buf) {
-        bf16* halo = reinterpret_cast<bf16*>(buf);
-        const bool pro = (ci < nch0) && (p.aff0 != nullptr);
-        float pa[8], pb[8];
-        if (pro) {
-            const float* af = p.aff0 + ((size_t)b * p.C[0] + ci * KC + c8 * 8) * 2;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                pa[j] = af[2 * j];
-                pb[j] = af[2 * j + 1];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NH; i++) {
-            if (loff[i] >= 0) {
-                Frag<bf16> v = hreg[i];
-                if (pro) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) frag_set<bf16>(v, j, silu_f(pa[j] * frag_get<bf16>(v, j) + pb[j]));
-                }
-                if (!hval[i]) frag_zero<bf16>(v);
-                frag_store<bf16>(v, halo + loff[i]);
-            }
-        }
-    };
-    // ---- DMAH: halo piece q (slots 64q..64q+63) by wave q % NW; per piece the lane's source pixel, channel half and validity
+    const int hbe8 = ((4 * pg + 2) * HALO_W + col + 2) * 32 + ((g & 1) << 4);  // tap 8 (ky = kx = 2)
+
+    // ---- halo piece q (slots 64q..64q+63) by wave q % NW; per piece the lane's source pixel, channel half and validity
     constexpr int HPW = (Cfg::HPIECES + NW - 1) / NW;  // pieces per wave (3 for both tile heights)
     int dpix[HPW];
     bool dval[HPW];
     int dhalf[HPW];
-    if constexpr (DMAH) {
+    {
 #pragma unroll
         for (int i = 0; i < HPW; i++) {
             const int slot = (wave + i * NW) * 64 + lane;
@@ -167,10 +130,10 @@ template <int NW, bool DMAH> __global__ __launch_bounds__(64 * NW, 2) void conv3
             const int sy = p.up2 ? Yc >> 1 : Yc, sx = p.up2 ? Xc >> 1 : Xc;
             dpix[i] = sy * Ws + sx;
             dhalf[i] = h ^ (hy & 1);
-            // slots that no DMA ever writes (outside the image, or the tail of the last piece) are zeroed once, in both buffers
+            // slots that no DMA ever writes (outside the image, or the tail of the last piece) are zeroed once, in all three buffers
             if (!dval[i] && (wave + i * NW) < Cfg::HPIECES) {
-                *reinterpret_cast<i32x4*>(smem + (wave + i * NW) * 1024 + lane * 16) = i32x4{0, 0, 0, 0};
-                *reinterpret_cast<i32x4*>(smem + BUF_BYTES + (wave + i * NW) * 1024 + lane * 16) = i32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 3; k++) *reinterpret_cast<i32x4*>(smem + k * HALO_BYTES + (wave + i * NW) * 1024 + lane * 16) = i32x4{0, 0, 0, 0};
             }
         }
     }
@@ -187,181 +150,222 @@ template <int NW, bool DMAH> __global__ __launch_bounds__(64 * NW, 2) void conv3
             }
         }
     };
-    // ---- weight chunk: 36 pieces of 1 KB, global -> LDS directly, piece q by wave q % 8
-    auto wload = [&](int ci, unsigned char* buf) {
-        const unsigned char* slab = wbase + (size_t)ci * WSLAB_BYTES;
-        unsigned char* wl = buf + HALO_BYTES;
-        for (int q = wave; q < WSLAB_BYTES / 1024; q += NW)
-            __builtin_amdgcn_global_load_lds((glb_void*)(slab + q * 1024 + lane * 16), (lds_void*)(wl + q * 1024), 16, 0, 0);
+    // ---- PRO: GroupNorm-apply + SiLU (ddp.py:160-166) of chunk ci, in place on the slots this lane's DMA wrote (out-of-image
+    // slots stay zero: the convolution pads the ACTIVATED tensor).  afl: this image's [C0][2] (a, b) table in LDS.
+    float* const afl = reinterpret_cast<float*>(smem + Cfg::AFF_OFF);
+    auto hpro = [&](int ci, unsigned char* buf, int i) {
+        if ((wave + i * NW) < Cfg::HPIECES && dval[i]) {
+            bf16x8* sp = reinterpret_cast<bf16x8*>(buf + (wave + i * NW) * 1024 + lane * 16);
+            bf16x8 v = *sp;
+            const float* af = afl + (ci * KC + dhalf[i] * 8) * 2;
+#pragma unroll
+            for (int j4 = 0; j4 < 4; j4++) {
+                const f32x4 ab = *reinterpret_cast<const f32x4*>(af + j4 * 4);
+                v[2 * j4] = (bf16)silu_f(ab[0] * (float)v[2 * j4] + ab[1]);
+                v[2 * j4 + 1] = (bf16)silu_f(ab[2] * (float)v[2 * j4 + 1] + ab[3]);
+            }
+            *sp = v;
+        }
+    };
+    // ---- weights of chunk ci: main slab (32 pieces of 1 KB) and, with every even chunk, the tap-8 slab of its pair (8 pieces);
+    // global -> LDS directly, piece q by wave q % NW
+    unsigned char* const wl = smem + Cfg::W_OFF;
+    auto wload = [&](int ci) {
+        const unsigned char* pair = wbase + (size_t)(ci >> 1) * PAIR_BYTES;
+        const unsigned char* slab = pair + (ci & 1) * WMAIN_BYTES;
+        unsigned char* dst = wl + (ci & 1) * WMAIN_BYTES;
+#ifdef DB_DMA_UNROLL1
+#pragma unroll 1
+#endif
+        for (int q = wave; q < WMAIN_BYTES / 1024; q += NW)
+            __builtin_amdgcn_global_load_lds((glb_void*)(slab + q * 1024 + lane * 16), (lds_void*)(dst + q * 1024), 16, 0, 0);
+        if (!(ci & 1)) {
+            const unsigned char* s8 = pair + 2 * WMAIN_BYTES;
+            unsigned char* d8 = wl + 2 * WMAIN_BYTES + ((ci >> 1) & 1) * W8_BYTES;
+#ifdef DB_DMA_UNROLL1
+#pragma unroll 1
+#endif
+            for (int q = wave; q < W8_BYTES / 1024; q += NW)
+                __builtin_amdgcn_global_load_lds((glb_void*)(s8 + q * 1024 + lane * 16), (lds_void*)(d8 + q * 1024), 16, 0, 0);
+        }
     };
 
-    wload(0, smem);
-    if constexpr (DMAH) {
-        hdma(0, smem);
-    } else {
-        gload(0);
-        lstore(0, smem);
+    wload(0);
+    hdma(0, smem);
+    if constexpr (PRO) {
+        const float* asrc = p.aff0 + (size_t)b * p.C[0] * 2;
+        for (int i = tid; i < p.C[0] / 2; i += NTHREADS) *reinterpret_cast<f32x4*>(afl + i * 4) = *reinterpret_cast<const f32x4*>(asrc + i * 4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
+        __syncthreads();                                   // the affine table is complete
+#pragma unroll
+        for (int i = 0; i < HPW; i++) hpro(0, smem, i);
     }
     __syncthreads();  // (drains the LDS-DMA as well: vmcnt(0))
-    const int bsw = (r >> 3) & 1;  // weight rows with bit 3 set keep their two 16-byte halves swapped
+    int hcur = 0;     // ring slot of the current chunk's halo
+    // Fragment pipeline, explicit: a K step is 4 groups of (2 weight fragments x 4 pixel fragments = 8 MFMAs); the fragments of
+    // group i+1 (and, at the end of a K step, the next step's pixel fragments) are read BEFORE the MFMAs of group i are issued.
+    // sched_barrier pins that order - left alone, hipcc sinks every LDS read down to its first use and the wave sits out a
+    // full LDS round trip every 8 MFMAs.
+    bf16x8 fa[2][2], fb[2][4];
+    auto LB = [&](bf16x8(&d)[4], const unsigned char* hb, int be) {
+        const int bo = (be + HALO_W * 32) ^ 16;
+#pragma unroll
+        for (int mr = 0; mr < 4; mr++) d[mr] = *reinterpret_cast<const bf16x8*>(hb + ((mr & 1) ? bo : be) + (mr >> 1) * (2 * HALO_W * 32));
+    };
+    auto LA = [&](bf16x8(&d)[2], const unsigned char* wp, int gq) {
+        d[0] = *reinterpret_cast<const bf16x8*>(wp + (2 * gq) * 1024);
+        d[1] = *reinterpret_cast<const bf16x8*>(wp + (2 * gq + 1) * 1024);
+    };
+    auto MM = [&](const bf16x8(&a2)[2], const bf16x8(&b4)[4], int gq) {
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int mr = 0; mr < 4; mr++) acc[2 * gq + t][mr] = mma32(a2[t], b4[mr], acc[2 * gq + t][mr]);
+    };
     for (int ci = 0; ci < nch; ci++) {
-        unsigned char* cur = smem + (ci & 1) * BUF_BYTES;
-        unsigned char* nxt = smem + ((ci & 1) ^ 1) * BUF_BYTES;
+        const int hnxt = hcur == 2 ? 0 : hcur + 1, hprv = hcur == 0 ? 2 : hcur - 1;
+        const unsigned char* halo = smem + hcur * HALO_BYTES;
+        unsigned char* hnext = smem + hnxt * HALO_BYTES;
+        const unsigned char* wm = wl + (ci & 1) * WMAIN_BYTES + woff;
         const bool more = ci + 1 < nch;
-#ifdef DB_TRACE
-        unsigned long long db_t[5];
-#endif
-        DB_STAMP(0)
-        DB_STAMP(1)
-        const bf16* halo = reinterpret_cast<const bf16*>(cur);
-        const unsigned char* wl = cur + HALO_BYTES;
+        // tap 8 of the chunk pair (2P, 2P+1) is ONE K step, in the odd period: K groups 0,1 read chunk 2P's halo (still in the
+        // ring), K groups 2,3 this chunk's.  A lone last chunk pairs with zeros (its slab's upper slots are zero too).
+        const bool has8 = (ci & 1) || !more, lone = !(ci & 1);
+        const unsigned char* w8 = wl + 2 * WMAIN_BYTES + ((ci >> 1) & 1) * W8_BYTES + woff;
+        const unsigned char* h8 = smem + (lone ? hcur : ((g >> 1) ? hcur : hprv)) * HALO_BYTES;
+        LB(fb[0], halo, hbe[0]);
+        LA(fa[0], wm, 0);
 #pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            const int ky = tap / 3, kx = tap - ky * 3;
-            Frag<bf16> fa[2], fb[4];
-#ifdef DB_NO_FRAG  // ablation build: no fragment reads (the MFMAs run on whatever the registers hold)
+        for (int q = 0; q < 4; q++) {
 #pragma unroll
-            for (int mr = 0; mr < 2; mr++) asm volatile("" : "=v"(fa[mr].v));
-#pragma unroll
-            for (int nr = 0; nr < 4; nr++) asm volatile("" : "=v"(fb[nr].v));
-#else
-#pragma unroll
-            for (int mr = 0; mr < 2; mr++) {
-                const int py = pg * 4 + mr * 2 + (r >> 4), px = r & 15;
-                if constexpr (DMAH)
-                    frag_load<bf16>(fa[mr], halo + ((py + ky) * HALO_W + px + kx) * KC + ((hf ^ ((py + ky) & 1)) << 3));
-                else
-                    frag_load<bf16>(fa[mr], halo + (py + ky) * HROW + (px + kx) * KCP + hf * 8);
-            }
-#pragma unroll
-            for (int nr = 0; nr < 4; nr++)
-                fb[nr].v = *reinterpret_cast<const bf16x8*>(wl + (tap * BN + nr * 32 + r) * 32 + ((hf ^ bsw) << 4));
-#endif
-#ifdef DB_NO_MFMA  // ablation build: fragment reads only
-#pragma unroll
-            for (int mr = 0; mr < 2; mr++) asm volatile("" ::"v"(fa[mr].v));
-#pragma unroll
-            for (int nr = 0; nr < 4; nr++) asm volatile("" ::"v"(fb[nr].v));
-#elif defined(DB_MFMA16)  // ablation build (wrong results): the same fragment reads feeding v_mfma_f32_16x16x32_bf16, 16 per tap
-#pragma unroll
-            for (int mr = 0; mr < 2; mr++)
-#pragma unroll
-                for (int nr = 0; nr < 4; nr++)
-#pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        const int sub = (tap & 1) * 2 + q;
-                        f32x4 t = {acc[mr][nr][4 * sub], acc[mr][nr][4 * sub + 1], acc[mr][nr][4 * sub + 2], acc[mr][nr][4 * sub + 3]};
-                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mr].v, fb[nr].v, t, 0, 0, 0);
-#pragma unroll
-                        for (int e = 0; e < 4; e++) acc[mr][nr][4 * sub + e] = t[e];
+            for (int gq = 0; gq < 4; gq++) {
+                if (gq < 3) {
+                    LA(fa[(gq + 1) & 1], wm + q * (BN * 64), gq + 1);
+                } else if (q < 3) {
+                    LA(fa[0], wm + (q + 1) * (BN * 64), 0);
+                    LB(fb[(q + 1) & 1], halo, hbe[q + 1]);
+                } else if (has8) {
+                    LA(fa[0], w8, 0);
+                    LB(fb[0], h8, hbe8);
+                }
+                DB_FENCE;
+                MM(fa[gq & 1], fb[q & 1], gq);
+                DB_FENCE;
+                if (q == 0 && gq == 0 && more) {  // next chunk's loads go out once the MFMA pipe has work queued behind the barrier
+                    wload(ci + 1);
+                    hdma(ci + 1, hnext);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // the prologue of the NEXT chunk, one DMA piece per MFMA group, late in the period (the pieces were issued at its
+                // start); the two wave halves do it in different K steps so that they do not all leave the matrix pipe at once
+                if constexpr (PRO) {
+                    if (q == (wave < NW / 2 ? 3 : 2) && gq < HPW && more && ci + 1 < nch0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (gq == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        hpro(ci + 1, hnext, gq);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-#else
-#pragma unroll
-            for (int mr = 0; mr < 2; mr++)
-#pragma unroll
-                for (int nr = 0; nr < 4; nr++) mma16<bf16>(acc[mr][nr], fa[mr], fb[nr]);
-#endif
-            if (tap == DB_TAP_ISSUE && more) {  // next chunk's loads go out once the MFMA pipe has work queued behind the barrier
-                wload(ci + 1, nxt);
-                if constexpr (DMAH) hdma(ci + 1, nxt);
-                else gload(ci + 1);
-            }
-            // the halo registers go to LDS inside the MFMA sequence (the partner wave of the SIMD keeps the pipe busy
-            // meanwhile); the two wave halves do it at different taps so that they do not all leave the pipe at once
-            if constexpr (!DMAH) {
-                if (tap == (wave < NW / 2 ? DB_TAP_STORE_A : DB_TAP_STORE_B) && more) lstore(ci + 1, nxt);
+                }
             }
         }
-        DB_STAMP(2)
-        DB_STAMP(3)
+        if (has8) {
+            if (lone && (g >> 1)) {
+#pragma unroll
+                for (int mr = 0; mr < 4; mr++) fb[0][mr] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                if (gq < 3) LA(fa[(gq + 1) & 1], w8, gq + 1);
+                DB_FENCE;
+                MM(fa[gq & 1], fb[0], gq);
+                DB_FENCE;
+            }
+        }
         __syncthreads();
-        DB_STAMP(4)
-#ifdef DB_TRACE
-        if (NW == 8 && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && ci < 64)
-            for (int s_ = 0; s_ < 5; s_++) db_trace[(wave * 64 + ci) * 8 + s_] = db_t[s_];
-#endif
+        hcur = hnxt;
     }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last MFMA retired before the accumulators are read (see conv3x3.hip)
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- epilogue: +bias, GroupNorm partials from the fp32 accumulators, output tile transposed through LDS (fp32, one
-    // 128-pixel half at a time) so that HBM sees 16-byte stores of 8 consecutive channels.
-    float* ot = reinterpret_cast<float*>(smem);
-    float cs[4] = {0.f, 0.f, 0.f, 0.f}, css[4] = {0.f, 0.f, 0.f, 0.f};
+    // ---- epilogue from the accumulators: lane (pixel column col, row group g) holds, for every tile pair j, the 8 consecutive
+    // channels n0 + 32j + 8g .. +7 of its pixel in each of the wave's 4 rows: + bias, GroupNorm sums of the fp32 values, bf16.
+    // Stored straight from these registers a wave instruction would write 64 scattered 64-byte pieces (measured: 18 us per
+    // launch, three times the LDS-staged epilogue of the 32x32x16 kernel), so the 16-byte vectors take a turn through the wave's
+    // OWN 64 x 272-byte LDS rows (no block barrier: every wave is past the loop's last one) and leave as whole 256-byte pixel rows.
+    constexpr int EROW = 2 * BN + 16;  // bytes per staged pixel (+16: the 8 lanes that ds_write_b128 serves together hit 8 bank groups)
+    unsigned char* const est = smem + wave * (64 * EROW);
+    float cs[4], css[4];
 #pragma unroll
-    for (int mr = 0; mr < 2; mr++) {
+    for (int j = 0; j < 4; j++) {
+        cs[j] = css[j] = 0.f;
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 32 * j + 8 * g), b1 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 32 * j + 8 * g + 4);
 #pragma unroll
-        for (int nr = 0; nr < 4; nr++) {
-            const int nl = nr * 32 + r;
-            const float bias = p.bias[n0 + nl];
+        for (int mr = 0; mr < 4; mr++) {
+            const int Y = ty0 + 4 * pg + mr, X = tx0 + col;
+            float v[8];
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int row = acc_row(e, lane);
-                const int Y = ty0 + pg * 4 + mr * 2 + (row >> 4), X = tx0 + (row & 15);
-                const float v = acc[mr][nr][e] + bias;
-                ot[(pg * 32 + row) * OS + nl] = v;
-                if (Y < p.H && X < p.W) {
-                    cs[nr] += v;
-                    css[nr] += v * v;
-                }
+            for (int e = 0; e < 4; e++) {
+                v[e] = acc[2 * j][mr][e] + b0[e];
+                v[4 + e] = acc[2 * j + 1][mr][e] + b1[e];
             }
-        }
-        __syncthreads();
-        for (int idx = tid; idx < NW * 32 * (BN / 8); idx += NTHREADS) {
-            const int pl = idx / (BN / 8), v8 = idx - pl * (BN / 8);
-            const int wv = pl >> 5, row = pl & 31;
-            const int Y = ty0 + wv * 4 + mr * 2 + (row >> 4), X = tx0 + (row & 15);
+            *reinterpret_cast<bf16x8*>(est + (mr * 16 + col) * EROW + j * 64 + g * 16) =
+                bf16x8{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
             if (Y < p.H && X < p.W) {
-                const float* sp = ot + pl * OS + v8 * 8;
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(sp), hi = *reinterpret_cast<const f32x4*>(sp + 4);
-                Frag<bf16> f;
-                f.v = bf16x8{(bf16)lo[0], (bf16)lo[1], (bf16)lo[2], (bf16)lo[3], (bf16)hi[0], (bf16)hi[1], (bf16)hi[2], (bf16)hi[3]};
-                frag_store<bf16>(f, p.out + (((size_t)b * p.H + Y) * p.W + X) * p.Cout + n0 + v8 * 8);
-            }
-        }
-        __syncthreads();
-    }
-    if (p.stats != nullptr) {
-        float* st = reinterpret_cast<float*>(smem);  // [pixel group][half][BN][2], then [BN][2]
-        float* col = st + NW * 2 * BN * 2;
 #pragma unroll
-        for (int nr = 0; nr < 4; nr++) {
-            float* d = st + (((pg * 2 + hf) * BN) + nr * 32 + r) * 2;
-            d[0] = cs[nr];
-            d[1] = css[nr];
-        }
-        __syncthreads();
-        // One partial per 16-row sub-tile (NS per block), each summed in the order the 16-row kernel uses for that sub-tile:
-        // the two tile heights write bit-identical statistics, so the launch heuristic cannot break batch invariance.
-        constexpr int NS = NW / 4;
-        if (tid < BN) {
-#pragma unroll
-            for (int ns = 0; ns < NS; ns++) {
-                float s = 0.f, ss = 0.f;
-#pragma unroll
-                for (int k = ns * 8; k < ns * 8 + 8; k++) {  // fixed order -> deterministic
-                    s += st[(k * BN + tid) * 2];
-                    ss += st[(k * BN + tid) * 2 + 1];
+                for (int e = 0; e < 8; e++) {
+                    cs[j] += v[e];
+                    css[j] += v[e] * v[e];
                 }
-                col[(ns * BN + tid) * 2] = s;
-                col[(ns * BN + tid) * 2 + 1] = ss;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifndef DB_NOSTORE
+#pragma unroll
+    for (int i = 0; i < 16; i++) {  // 4 pixels x 256 bytes per wave instruction
+        const int pix = i * 4 + (lane >> 4), v16 = lane & 15;
+        const int Y = ty0 + 4 * pg + (pix >> 4), X = tx0 + (pix & 15);
+        if (Y < p.H && X < p.W)
+            *reinterpret_cast<bf16x8*>(p.out + (((size_t)b * p.H + Y) * p.W + X) * p.Cout + n0 + v16 * 8) = *reinterpret_cast<const bf16x8*>(est + pix * EROW + v16 * 16);
+    }
+#endif
+    if (p.stats != nullptr) {
+        // per wave and 8-channel vector (j, g): sums over the wave's 4 x 16 pixels (xor tree over the 16 pixel columns), then
+        // - fixed order, so deterministic - over the 4 waves of a 16-row sub-tile and the vectors of a GroupNorm group.  One
+        // partial per 16x16 pixels from either tile height, summed the same way: the launch heuristic cannot change a bit.
+        float* st = reinterpret_cast<float*>(smem + NW * (64 * EROW));  // [wave][16 vectors][2], behind the staging rows
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                cs[j] += __shfl_xor(cs[j], o, 64);
+                css[j] += __shfl_xor(css[j], o, 64);
+            }
+            if (col == 0) {
+                st[((pg * 16) + j * 4 + g) * 2] = cs[j];
+                st[((pg * 16) + j * 4 + g) * 2 + 1] = css[j];
             }
         }
         __syncthreads();
+        constexpr int NS = NW / 4;
         const int cpg = p.Cout / p.groups;
-        const int gpt = BN / cpg;  // groups covered by this N tile (host guarantees cpg | BN)
+        const int gpt = BN / cpg;  // groups covered by this N tile (host guarantees cpg | BN and 8 | cpg)
+        const int vpg = cpg / 8;   // 8-channel vectors per group
         if (tid < gpt * NS) {
             const int ns = tid / gpt, gi = tid - ns * gpt;
-            const int g = (n0 / cpg) + gi;
+            const int grp = (n0 / cpg) + gi;
             const int ty16 = (tile / p.tiles_x) * NS + ns, rows16 = (p.H + 15) / 16;
-            if (g < p.groups && ty16 < rows16) {
+            if (grp < p.groups && ty16 < rows16) {
                 float s = 0.f, ss = 0.f;
-                for (int c = 0; c < cpg; c++) {
-                    s += col[(ns * BN + gi * cpg + c) * 2];
-                    ss += col[(ns * BN + gi * cpg + c) * 2 + 1];
-                }
-                float* dst = p.stats + (((size_t)b * p.groups + g) * (rows16 * p.tiles_x) + ty16 * p.tiles_x + (tile % p.tiles_x)) * 2;
+                for (int k = 0; k < 4; k++)
+                    for (int v = 0; v < vpg; v++) {
+                        s += st[(((ns * 4 + k) * 16) + gi * vpg + v) * 2];
+                        ss += st[(((ns * 4 + k) * 16) + gi * vpg + v) * 2 + 1];
+                    }
+                float* dst = p.stats + (((size_t)b * p.groups + grp) * (rows16 * p.tiles_x) + ty16 * p.tiles_x + (tile % p.tiles_x)) * 2;
                 dst[0] = s;
                 dst[1] = ss;
             }
@@ -390,6 +394,11 @@ int conv3x3_db_launch(const dig_conv3x3_args* a, hipStream_t stream) {
     p.bstride0 = a->in0_bstride > 0 ? a->in0_bstride : (long long)(a->up2 ? (a->H / 2) * (a->W / 2) : a->H * a->W) * a->C0;
     p.B = a->B; p.H = a->H; p.W = a->W; p.Cout = a->Cout; p.groups = a->groups; p.up2 = a->up2;
     p.tiles_x = cdiv(a->W, 16);
+    if (a->stats) {
+        const int cpg = a->Cout / a->groups;
+        DIG_CHECK(cpg % 8 == 0, DIG_EINVAL, "conv3x3(db): GroupNorm group width %d must be a multiple of 8", cpg);
+    }
+    DIG_CHECK(((uintptr_t)a->bias) % 16 == 0, DIG_EALIGN, "conv3x3(db): bias must be 16-byte aligned");
     static std::atomic<int> ncu[64];  // zero-initialised; racing first calls all store the same values
     int device = 0;
     (void)hipGetDevice(&device);
@@ -398,8 +407,8 @@ int conv3x3_db_launch(const dig_conv3x3_args* a, hipStream_t stream) {
     if (!ncus) {
         hipError_t e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<8>::DB_LDS);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<4>::DB_LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (DbCfg<8, true>::DB_LDS));
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (DbCfg<4, true>::DB_LDS));
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<8>::DB_LDS_PRO);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<4>::DB_LDS_PRO);
         DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "conv3x3(db): cannot raise dynamic LDS to %d: %s", DbCfg<8>::DB_LDS, hipGetErrorString(e));
         int n = 0;
         e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device);
@@ -407,25 +416,19 @@ int conv3x3_db_launch(const dig_conv3x3_args* a, hipStream_t stream) {
         ncu[dev].store(n, std::memory_order_release);
         ncus = n;
     }
-    // 32-row tiles unless they would leave CUs without a block (one block per CU: 143 KB of LDS); then 16-row tiles, 4 waves
+    // 32-row tiles unless they would leave CUs without a block (one block per CU: 140 KB of LDS); then 16-row tiles, 4 waves
     const long long grid32 = (long long)a->B * p.tiles_x * cdiv(a->H, 32) * (a->Cout / BN);
-    const char* force = getenv("DIG_DB_TILE");  // test hook, read per call: "16" / "32"
+    const char* force = getenv("DIG_DB_TILE");  // test hook, read per call (the tests flip it inside one process): "16" / "32"
     const bool small = force ? atoi(force) == 16 : grid32 < ncus;
-    // halo by LDS-DMA when no prologue has to touch it (DIG_DB_NO_HDMA: test hook, keeps the register-staged path)
-    const bool dmah = a->aff0 == nullptr && getenv("DIG_DB_NO_HDMA") == nullptr;
+    const bool pro = a->aff0 != nullptr;  // GroupNorm-apply + SiLU prologue on the channels of in0
+    DIG_CHECK(!pro || (a->C0 <= DbCfg<8>::AFF_MAX_C && ((uintptr_t)a->aff0) % 16 == 0), DIG_EINVAL,
+              "conv3x3(db): a prologue needs C0 <= %d and a 16-byte aligned aff0 (C0 = %d)", DbCfg<8>::AFF_MAX_C, a->C0);
     p.tiles_y = cdiv(a->H, small ? 16 : 32);
     const dim3 grid(a->B * p.tiles_x * p.tiles_y, a->Cout / BN);
-    constexpr int lds4 = DbCfg<4>::DB_LDS, lds4d = DbCfg<4, true>::DB_LDS, lds8 = DbCfg<8>::DB_LDS, lds8d = DbCfg<8, true>::DB_LDS;
-    if (small && dmah) hipLaunchKernelGGL((conv3x3_db_kernel<4, true>), grid, dim3(256), lds4d, stream, p);
-    else if (small) hipLaunchKernelGGL((conv3x3_db_kernel<4, false>), grid, dim3(256), lds4, stream, p);
-    else if (dmah) hipLaunchKernelGGL((conv3x3_db_kernel<8, true>), grid, dim3(512), lds8d, stream, p);
-    else hipLaunchKernelGGL((conv3x3_db_kernel<8, false>), grid, dim3(512), lds8, stream, p);
+    if (small && pro) hipLaunchKernelGGL((conv3x3_db_kernel<4, true>), grid, dim3(256), DbCfg<4>::DB_LDS_PRO, stream, p);
+    else if (small) hipLaunchKernelGGL((conv3x3_db_kernel<4, false>), grid, dim3(256), DbCfg<4>::DB_LDS, stream, p);
+    else if (pro) hipLaunchKernelGGL((conv3x3_db_kernel<8, true>), grid, dim3(512), DbCfg<8>::DB_LDS_PRO, stream, p);
+    else hipLaunchKernelGGL((conv3x3_db_kernel<8, false>), grid, dim3(512), DbCfg<8>::DB_LDS, stream, p);
     DIG_LAUNCH_CHECK("conv3x3(db)");
     return DIG_OK;
 }
-
-#ifdef DB_TRACE
-extern "C" int dig_debug_db_trace(unsigned long long* host) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(db_trace), sizeof(unsigned long long) * 8 * 64 * 8);
-}
-#endif

@@ -36,14 +36,43 @@ class ConvWeight:
         nch = w.shape[2] // KC
         w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, (-Co) % BN))  # pad Cout to a multiple of BN
         nt = w.shape[0] // BN
-        w = w.reshape(nt, BN, 9, nch, KC).permute(0, 3, 2, 1, 4).contiguous()
-        if _lib.lib().dig_conv3x3_wlayout(C0, C1, Co, dtype_code(dtype)) == 1:
-            assert KC == 16
-            rows = (torch.arange(BN, device=w.device) >> 3) & 1 == 1
-            w[:, :, :, rows, :] = torch.cat([w[:, :, :, rows, 8:], w[:, :, :, rows, :8]], -1)
+        layout = _lib.lib().dig_conv3x3_wlayout(C0, C1, Co, dtype_code(dtype))
+        if layout == 2:
+            w = _pack_pairs(w, nt, nch, BN, KC)
+        else:
+            w = w.reshape(nt, BN, 9, nch, KC).permute(0, 3, 2, 1, 4).contiguous()
+            if layout == 1:
+                assert KC == 16
+                rows = (torch.arange(BN, device=w.device) >> 3) & 1 == 1
+                w[:, :, :, rows, :] = torch.cat([w[:, :, :, rows, 8:], w[:, :, :, rows, :8]], -1)
         self.w = w.to(dtype)
         self.bias = bias.detach().float().contiguous()
         self.Cout, self.C0, self.C1, self.dtype = Co, C0, C1, dtype
+
+
+def _pack_pairs(w, nt, nch, BN, KC):
+    """The LDS image of conv3x3_db.hip (dig_conv3x3_wlayout == 2; K = 32 of one v_mfma_f32_16x16x32_bf16 = two taps x 16
+    channels).  w: [nt*BN][9 taps][nch*KC] fp32 -> [nt][pair P][main(2P) | main(2P+1) | w8(P)]:
+      main(c): [4 K steps q][128 rows][4 slots][8]  slot s = tap 2q + (s >> 1), channel half s & 1 of chunk c
+      w8(P)  : [128 rows][4 slots][8]               slot s = tap 8 of chunk 2P + (s >> 1), channel half s & 1
+    row rho = mt*16 + rr holds output channel 32*(mt >> 1) + 8*(rr >> 2) + 4*(mt & 1) + (rr & 3); slot s sits at position
+    s ^ f[(rho >> 2) & 3], f = (0, 2, 3, 1).  An odd chunk count is padded with a zero chunk."""
+    assert BN == 128 and KC == 16
+    dev = w.device
+    npairs = (nch + 1) // 2
+    w = torch.nn.functional.pad(w, (0, npairs * 32 - nch * KC))
+    rho = torch.arange(BN, device=dev)
+    mt, rr = rho >> 4, rho & 15
+    ch = 32 * (mt >> 1) + 8 * (rr >> 2) + 4 * (mt & 1) + (rr & 3)
+    wp = w.reshape(nt, BN, 9, npairs, 2, 2, 8)[:, ch]  # [nt][rho][tap][P][chunk in pair][half][8]
+    main = wp[:, :, :8].reshape(nt, BN, 4, 2, npairs, 2, 2, 8).permute(0, 4, 5, 2, 1, 3, 6, 7)  # [nt][P][cip][q][rho][tsel][half][8]
+    main = main.reshape(nt, npairs, 2, 4, BN, 4, 8)
+    w8 = wp[:, :, 8].permute(0, 2, 1, 3, 4, 5).reshape(nt, npairs, BN, 4, 8)  # [nt][P][rho][(cip, half)][8]
+    f = torch.tensor([0, 2, 3, 1], device=dev)[(rho >> 2) & 3]
+    src = torch.arange(4, device=dev)[None, :] ^ f[:, None]  # physical slot s' of row rho holds logical slot s' ^ f(rho)
+    main = torch.gather(main, 5, src[None, None, None, None, :, :, None].expand_as(main))
+    w8 = torch.gather(w8, 3, src[None, None, :, :, None].expand_as(w8))
+    return torch.cat([main.reshape(nt, npairs, -1), w8.reshape(nt, npairs, -1)], 2).contiguous()
 
 
 def conv3x3(x0, cw, x1=None, aff=None, up2=False, want_stats=True, groups=GN_GROUPS):

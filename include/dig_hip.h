@@ -52,9 +52,12 @@ typedef struct {
     int B, H, W, C0, C1, Cout, groups, up2, dtype;
 } dig_conv3x3_args;
 int dig_conv3x3_tiles(int H, int W, int C0, int C1, int Cout, int groups, int dtype);
-/* Row layout of the packed weight slabs for this layer: 0 = plain [..][BN][KC]; 1 = the two 16-byte halves of a row are
- * swapped when bit 3 of the row index is set (the LDS image of the double-buffered wide-layer kernel, which copies the
- * slabs global -> LDS without touching them). */
+/* Layout of the packed weight slabs for this layer: 0 = plain [n_tile][chunk][9 taps][BN][KC]; 2 = the LDS image of the
+ * double-buffered wide-layer kernel (conv3x3_db.hip), which copies the slabs global -> LDS without touching them:
+ * per 128-channel N tile and per PAIR of 16-channel chunks  main(2P) | main(2P+1) | w8(P), K = 32 of one
+ * v_mfma_f32_16x16x32_bf16 = two taps x 16 channels, rows permuted so that a lane's accumulators are 8 consecutive
+ * output channels, 16-byte slots XOR-swizzled for conflict-free ds_read_b128 (exact definition: dig_amd/ops.py:_pack_pairs;
+ * 1 was the 32x32x16 image of rounds 1-2). */
 int dig_conv3x3_wlayout(int C0, int C1, int Cout, int dtype);
 int dig_conv3x3_config(int Cout, int dtype, int* BN, int* KC);
 int dig_conv3x3(const dig_conv3x3_args* a, void* stream);
