@@ -247,7 +247,24 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import dig_oracle as O
-        cores = min(16, os.cpu_count() or 1)
+        # Threads: the GPU box hands a 1-GPU job a 16-CPU share of the host (OMP_NUM_THREADS = 16 there; os.cpu_count() shows
+        # the whole machine); the baseline uses that share, and the line states what the host shows beside it.
+        host_cpus = os.cpu_count() or 1
+        try:
+            affinity = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            affinity = host_cpus
+        share = int(os.environ.get("OMP_NUM_THREADS", "16") or 16)
+        cores = max(1, min(share, affinity, host_cpus))
+        cpu_model = "unknown"
+        try:
+            with open("/proc/cpuinfo") as f:
+                for line in f:
+                    if line.startswith("model name"):
+                        cpu_model = line.split(":", 1)[1].strip()
+                        break
+        except OSError:
+            pass
         torch.set_num_threads(cores)
         cx, cn, ct = x0[:1].cpu(), nz[:1].cpu(), t[:1].cpu()
         ox, ov, of = O.p_losses_eval(cpu_sd, cx, ct, cn)  # warm-up; doubles as the parity check of image 0 of the timed batch
@@ -267,6 +284,8 @@ def main():
             n_done += 1
         csec = (time.perf_counter() - c0) / n_done
         cpu = {"value": round(1.0 / csec, 3), "unit": "maps/s", "cores": cores, "kind": "port",
+               "host": {"cpu_model": cpu_model, "cpus_visible": host_cpus, "cpus_in_affinity_mask": affinity,
+                        "threads_used": cores, "why": "the job's CPU share on the GPU box (OMP_NUM_THREADS), not the whole machine"},
                "sample": f"{n_done} x (B=1, {S}x{S}, t={args.t}) fp32 forwards of oracle/dig_oracle.py (torch CPU ops), {csec*1e3:.0f} ms each"}
 
     if rank == 0:

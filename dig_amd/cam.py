@@ -191,9 +191,11 @@ def mctformer_forward(m, img, n_layers=12, feat_diff=None, flip_tta=False):
     flip_tta: run the batch [img, img.flip(-1)] (2B rows; the mirrored half is formed by the patch im2row kernel)."""
     if not img.is_cuda:
         raise RuntimeError("dig_amd.MCTformerV2_DiG runs on the HIP device only (no CPU fallback)")
-    from .diffusion import _same_device
-    _same_device(m, img.device, "MCTformerV2_DiG")
     P = _pack(m)
+    if P.get("device_checked") != img.device:  # once per packing: a move or an in-place update of any parameter re-packs
+        from .diffusion import _same_device
+        _same_device(m, img.device, "MCTformerV2_DiG")
+        P["device_checked"] = img.device
     Bi, _, H, W = img.shape
     B = 2 * Bi if flip_tta else Bi
     assert not (flip_tta and feat_diff is not None)

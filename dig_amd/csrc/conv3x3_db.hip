@@ -329,7 +329,15 @@ template <int NW, bool PRO> __global__ __launch_bounds__(64 * NW, 2) void conv3x
         const int pix = i * 4 + (lane >> 4), v16 = lane & 15;
         const int Y = ty0 + 4 * pg + (pix >> 4), X = tx0 + (pix & 15);
         if (Y < p.H && X < p.W)
-            *reinterpret_cast<bf16x8*>(p.out + (((size_t)b * p.H + Y) * p.W + X) * p.Cout + n0 + v16 * 8) = *reinterpret_cast<const bf16x8*>(est + pix * EROW + v16 * 16);
+        {
+            const bf16x8 ov = *reinterpret_cast<const bf16x8*>(est + pix * EROW + v16 * 16);
+            bf16x8* op = reinterpret_cast<bf16x8*>(p.out + (((size_t)b * p.H + Y) * p.W + X) * p.Cout + n0 + v16 * 8);
+#ifdef DB_NT_STORE
+            __builtin_nontemporal_store(ov, op);
+#else
+            *op = ov;
+#endif
+        }
     }
 #endif
     if (p.stats != nullptr) {

@@ -35,6 +35,13 @@
 #include <cstdlib>
 #include <type_traits>
 
+// This kernel reads the generic kernel's weight packing [chunk][9 taps][64][16] (BN = 64, KC = 16) and writes one GroupNorm
+// partial per 16x16 tile (TH = 4 * CONV_WPG64 = 16 in dig_conv3x3_tiles): a variant build that overrides the generic kernel's
+// tile macros (tools/lab/build_variant.sh) would silently disagree with it.
+#if (defined(CONV_KC64) && CONV_KC64 != 16) || (defined(CONV_WPG64) && CONV_WPG64 != 4)
+#error "conv3x3_rs128 assumes CONV_KC64 == 16 and CONV_WPG64 == 4 (the generic kernel's default packing and tile height)"
+#endif
+
 namespace {
 
 constexpr int HPIX = 18 * 18;

@@ -522,7 +522,17 @@ template <typename T, int KS> int launch_kvctx(const dig_la_kvctx_args* a, hipSt
     constexpr int C = KS * 16;
     const size_t lds = (size_t)2 * 64 * (C + 8) * sizeof(T);  // double-buffered pixel tile
     constexpr bool WREG = sizeof(T) == 2 || KS <= 4;  // k/v weight fragments live in registers (fp32 fragments are twice as large)
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)la_kv_ctx_kernel<T, KS, WREG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) {  // once per device and instantiation (not per call: the launchers must stay capture-safe after a warm-up)
+        static std::atomic<bool> attr_set[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        dev &= 63;
+        if (!attr_set[dev].load(std::memory_order_acquire)) {
+            hipError_t e = hipFuncSetAttribute((const void*)la_kv_ctx_kernel<T, KS, WREG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "la_kvctx: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
+            attr_set[dev].store(true, std::memory_order_release);
+        }
+    }
     hipLaunchKernelGGL((la_kv_ctx_kernel<T, KS, WREG>), dim3(a->splits, a->B), dim3(256), lds, st, *a);
     return 0;
 }
@@ -601,7 +611,7 @@ static __device__ __align__(256) unsigned char la_scratch[LA_NOALLOC_PART_BYTES 
 
 #include <mutex>
 static std::mutex la_scratch_mu;
-static unsigned char* la_scratch_ptr[64] = {};  // per device: each GPU holds its own copy of the array at its own address
+static std::atomic<unsigned char*> la_scratch_ptr[64];  // per device: each GPU holds its own copy of the array at its own address
 
 extern "C" int dig_la_ctx_noalloc_max_slots(void) { return LA_NOALLOC_MAX_SLOTS; }
 
@@ -609,21 +619,25 @@ extern "C" int dig_la_ctx_noalloc(const dig_la_ctx_noalloc_args* a, void* stream
     hipStream_t st = (hipStream_t)stream_;
     DIG_CHECK(a && a->x && a->wkv && a->ctx, DIG_EINVAL, "la_ctx_noalloc: null pointer");
     DIG_CHECK(a->B > 0 && a->n > 0 && a->splits > 0 && a->hid == 128 && a->B <= 65535, DIG_EINVAL, "la_ctx_noalloc: bad shape (needs 4 heads x 32)");
+    DIG_CHECK(a->dtype == DIG_BF16 || a->dtype == DIG_F32, DIG_EINVAL, "la_ctx_noalloc: unknown dtype %d", a->dtype);
     DIG_CHECK((long long)a->B * a->splits <= LA_NOALLOC_MAX_SLOTS, DIG_EINVAL,
               "la_ctx_noalloc: B * splits = %lld exceeds the static scratch (%d slots); use dig_la_kvctx + dig_la_merge with a caller workspace",
               (long long)a->B * a->splits, LA_NOALLOC_MAX_SLOTS);
     int dev = 0;
     DIG_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, DIG_ELAUNCH, "la_ctx_noalloc: cannot query the current device");
-    unsigned char* base;
-    {
+    // per device, once: the array's device address (each GPU holds its own copy).  Published with release / read with acquire,
+    // so the steady state takes no lock; only the first calls on a device serialise on the mutex.
+    unsigned char* base = la_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!base) {
         std::lock_guard<std::mutex> lock(la_scratch_mu);
-        if (!la_scratch_ptr[dev]) {
+        base = la_scratch_ptr[dev].load(std::memory_order_relaxed);
+        if (!base) {
             void* ptr = nullptr;
             hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(la_scratch));
             DIG_CHECK(e == hipSuccess && ptr, DIG_ELAUNCH, "la_ctx_noalloc: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
-            la_scratch_ptr[dev] = (unsigned char*)ptr;
+            base = (unsigned char*)ptr;
+            la_scratch_ptr[dev].store(base, std::memory_order_release);
         }
-        base = la_scratch_ptr[dev];
     }
     dig_la_kvctx_args k;
     k.x = a->x; k.wkv = a->wkv;

@@ -15,14 +15,22 @@ CATEGORIES = ['background', 'aeroplane', 'bicycle', 'bird', 'boat', 'bottle', 'b
 
 
 def save_cam_dict(path, cam_dict, reference_format=False):
-    """Write {class index -> float32 [H, W]}.  Default: an .npz archive of plain arrays (one entry per class index), which
-    loads without executing anything.  reference_format=True writes what model.py:489-492 writes - np.save of the dict
+    """Write {class index -> float32 [H, W]}; returns the path written.  Default: an .npz archive of plain arrays (one entry
+    per class index), which loads without executing anything; a trailing '.npy' of `path` is replaced by '.npz'.  reference_format=True writes what model.py:489-492 writes - np.save of the dict
     itself, i.e. a pickle inside the .npy - for interchange with the reference's evaluation.py."""
     d = {int(k): np.asarray(v, np.float32) for k, v in cam_dict.items()}
+    path = str(path)
     if reference_format:
         np.save(path, d)
-    else:
-        np.savez(path if str(path).endswith(".npz") else str(path) + ".npz", **{str(k): v for k, v in d.items()})
+        return path if path.endswith(".npy") else path + ".npy"
+    # the reference call site passes name + '.npy' (model.py:489-492): the archive takes the SAME stem, <name>.npz, which is
+    # where do_python_eval looks first (never <name>.npy.npz)
+    if path.endswith(".npy"):
+        path = path[:-4]
+    if not path.endswith(".npz"):
+        path += ".npz"
+    np.savez(path, **{str(k): v for k, v in d.items()})
+    return path
 
 
 def load_cam_dict(path, reference_format=False):
@@ -33,6 +41,8 @@ def load_cam_dict(path, reference_format=False):
     if path.endswith(".npz"):
         with np.load(path, allow_pickle=False) as z:
             return {int(k): z[k] for k in z.files}
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path}: no such cam_dict file (looked for the .npz archive of the same stem first)")
     if not reference_format:
         raise ValueError(f"{path}: a reference-format .npy cam_dict is a pickle; pass reference_format=True to load it "
                          "(only for files you trust), or save with save_cam_dict(..., reference_format=False)")

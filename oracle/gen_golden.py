@@ -364,11 +364,31 @@ def case_state_dict_keys(ddp, mct):
     print("[state_dict_keys] " + "  ".join(f"{k}: {len(v)} entries" for k, v in tables.items()))
 
 
+def case_envelope_full(ddp, name, H, W, idx):
+    """The reference's own bf16-autocast error at the HEADLINE size (BASELINE.json configs[1]: 256x256, t = 100) on image `idx`
+    of the bench / test batch - numbers only (MANIFEST bf16_envelope), no arrays: the fp32 side of the comparison is the
+    oracle on the GPU box, the 1.5x bound of tests/test_gpu_unet.py needs just these maxima."""
+    gd = ref_diffusion(ddp, 64, H, flash=False)
+    x0 = synth.synth_images(32, H, W, seed=1234)[idx:idx + 1]
+    noise = synth.synth_noise(32, H, W, seed=1235)[idx:idx + 1]
+    t = torch.tensor([100], dtype=torch.long)
+    _, v, feats = gd.p_losses(x0, t, noise=noise.clone())
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        _, vb, fb = gd.p_losses(x0, t, noise=noise.clone())
+    env = {"v": maxabs(v, vb.float()), "v_absmax": float(v.abs().max())}
+    for i, (a, b) in enumerate(zip(feats, fb)):
+        env[f"feat{i}"] = maxabs(a, b.float())
+        env[f"feat{i}_absmax"] = float(a.abs().max())
+    ENVELOPE[name] = env
+    print(f"[{name}] reference bf16-autocast envelope: " + "  ".join(f"{k}={x:.3e}" for k, x in env.items()))
+
+
 def _merge_manifest():
     mp = os.path.join(GOLD, "MANIFEST.json")
     with open(mp) as f:
         man = json.load(f)
     man["cases"].update(MANIFEST)
+    man["bf16_envelope"].update(ENVELOPE)
     with open(mp, "w") as f:
         json.dump(man, f, indent=1)
 
@@ -394,6 +414,14 @@ def main():
         case_losses(mct, "losses224_c20", 20, 224, 224, 2, 14, 14)
         _merge_manifest()
         return
+    if sys.argv[1:] == ["envelope256"]:  # reference bf16-autocast envelope at the headline size (numbers only)
+        case_envelope_full(ref_import.load_ddp(), "unet256_t100_img0", 256, 256, 0)
+        _merge_manifest()
+        return
+    if sys.argv[1:] == ["voc"]:  # a VOC-sized CAM case (733 tokens): label maps pinned to the reference itself
+        case_cam(mct, "cam368x496_c20", 20, 368, 496, 1)
+        _merge_manifest()
+        return
     if sys.argv[1:] == ["eval"]:
         case_eval(ref_import.load_evaluation())
         _merge_manifest()
@@ -408,6 +436,8 @@ def main():
     case_cam(mct, "cam224_c20", 20, 224, 224, 1)
     case_cam(mct, "cam160x208_c20", 20, 160, 208, 1)
     case_cam(mct, "cam224_c80", 80, 224, 224, 1)
+    case_cam(mct, "cam368x496_c20", 20, 368, 496, 1)
+    case_envelope_full(ddp, "unet256_t100_img0", 256, 256, 0)
     case_lfca(mct, "lfca224_c20", 20, 224, 224, 14, 14)
     case_lfca(mct, "lfca224_c20_maps16", 20, 224, 224, 16, 16)  # guidance maps from a 256x256 diffusion input: bilinear 14 -> 16
     case_eval(ref_import.load_evaluation())

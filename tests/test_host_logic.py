@@ -148,6 +148,13 @@ def test_cam_dict_formats(tmp_path):
     with pytest.raises(ValueError, match="reference_format"):
         E.load_cam_dict(str(tmp_path / "b.npy"))
     assert np.array_equal(E.load_cam_dict(str(tmp_path / "b.npy"), reference_format=True)[17], d[17])
+    # the reference call site's file name (name + '.npy', model.py:489-492) lands on <name>.npz - where do_python_eval looks
+    # first - not on <name>.npy.npz; a missing file is reported as missing, not as a format problem
+    assert E.save_cam_dict(str(tmp_path / "c.npy"), d) == str(tmp_path / "c.npz")
+    assert (tmp_path / "c.npz").exists() and not (tmp_path / "c.npy.npz").exists() and not (tmp_path / "c.npy").exists()
+    assert np.array_equal(E.load_cam_dict(str(tmp_path / "c.npz"))[3], d[3])
+    with pytest.raises(FileNotFoundError):
+        E.load_cam_dict(str(tmp_path / "missing.npy"))
 
 
 def test_synth_is_deterministic_and_keyed():

@@ -137,6 +137,11 @@ def test_cam_c80(golden):
     _check_cam(golden, "cam224_c80", 80, 224, 224)
 
 
+def test_cam_voc_sized(golden):
+    """368x496 (733 tokens): the size class of the reference's inference loop; fixture = the reference's own label maps."""
+    _check_cam(golden, "cam368x496_c20", 20, 368, 496)
+
+
 def test_lfca_consumer(golden):
     """the LFCA branch (mctformer.py:56-166,265-291) - oracle restatement against the reference's outputs."""
     g = golden("lfca224_c20")
