@@ -303,13 +303,18 @@ template <int DH> __global__ __launch_bounds__(256, 1) void vit_attn_mfma_kernel
 //           global/L2 as a coalesced 128-byte read, and p is added into the head-sum [32][N | 1] in LDS (odd pitch: the
 //           32 query rows of one key hit 32 banks; every (q, key) is owned by exactly one lane, so no atomics).
 // The waves' partial O tiles meet in LDS once per head.  fp32 products and accumulation throughout, as in the kernel above.
+// GACC (N > 928: the head-sum row [32][N] no longer fits LDS - 368x496 at scale 1.5 / 2.0 of VOC12DatasetMS is 1573 / 2872
+// tokens, voc12/data.py:794-809): p / heads is added straight into acc_all (and acc_cls) once per head.  Every (q, key) is
+// still owned by exactly one lane of one block, so the read-modify-write needs no atomics; a lane's 16 keys of a tile are four
+// 16-byte pieces and the two lane halves of a query cover the tile's whole 128-byte line.  The old values are loaded at the
+// top of the tile, beside V, so their latency sits under the score MFMAs.
 constexpr int ATT_T_MAXN = 928;
-template <int DH> __global__ __launch_bounds__(256, 1) void vit_attn_tiled_kernel(dig_vit_attn_args a) {
+template <int DH, bool GACC> __global__ __launch_bounds__(256, 1) void vit_attn_tiled_kernel(dig_vit_attn_args a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int DT = DH / 32, NKS = DH / 16;
     const int N = a.N, nkt = (N + 31) / 32, PP = N | 1;
-    float* Pacc = sm;                       // [32][PP] sum over the heads of the probabilities
-    float* xb = Pacc + 32 * PP;             // [4 waves][DT][32 q][33] partial O tiles
+    float* Pacc = sm;                       // [32][PP] sum over the heads of the probabilities (not with GACC)
+    float* xb = Pacc + (GACC ? 0 : 32 * PP);  // [4 waves][DT][32 q][33] partial O tiles
     float* ml = xb + 4 * DT * 32 * 33;      // [8 = wave x half][32 q][2] partial (max, sum)
     float* mfin = ml + 8 * 32 * 2;          // [32 q][2] (max, 1 / sum) of the current head
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hf = lane >> 5;
@@ -319,7 +324,12 @@ template <int DH> __global__ __launch_bounds__(256, 1) void vit_attn_tiled_kerne
     const float* qkv = a.qkv + (size_t)b * N * D3;
     const float scale = rsqrtf((float)DH);
     const int qrow = min(q0 + r, N - 1);  // rows past the end repeat the last query; they are never stored
-    for (int i = tid; i < 32 * PP; i += 256) Pacc[i] = 0.f;
+    if constexpr (!GACC)
+        for (int i = tid; i < 32 * PP; i += 256) Pacc[i] = 0.f;
+    const float inv_nh = 1.0f / (float)a.heads;
+    const bool qvalid = q0 + r < N, cvalid = a.acc_cls != nullptr && q0 + r < a.ncls;
+    float* arow = a.acc_all + ((size_t)b * N + qrow) * N;
+    float* crow = a.acc_cls ? a.acc_cls + ((size_t)b * a.ncls + min(q0 + r, a.ncls - 1)) * N : nullptr;
     auto kload = [&](Frag<float>(&fk)[NKS], int kt, int h) {
         const int key = min(kt * 32 + r, N - 1);
 #pragma unroll
@@ -393,6 +403,14 @@ template <int DH> __global__ __launch_bounds__(256, 1) void vit_attn_tiled_kerne
 #pragma unroll
                 for (int dt = 0; dt < DT; dt++) vv[e][dt] = qkv[(size_t)key * D3 + 2 * Dm + h * DH + dt * 32 + r];
             }
+            float old[16];  // GACC: acc_all[q][key(e, hf)] before this head
+            if constexpr (GACC) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int key = kt * 32 + acc_row(e, lane);
+                    old[e] = (qvalid && key < N) ? arow[key] : 0.f;
+                }
+            }
             f32x16 s;
             scores(s, fk, fq, kt);
 #pragma unroll
@@ -400,7 +418,14 @@ template <int DH> __global__ __launch_bounds__(256, 1) void vit_attn_tiled_kerne
                 const int key = kt * 32 + acc_row(e, lane);
                 const float p = expf(s[e] - m) * linv;  // exp(-inf) = 0 for the keys past the end
                 s[e] = p;
-                if (key < N) Pacc[r * PP + key] += p;
+                if constexpr (GACC) {
+                    if (qvalid && key < N) {
+                        arow[key] = old[e] + p * inv_nh;
+                        if (cvalid) crow[key] += p * inv_nh;
+                    }
+                } else {
+                    if (key < N) Pacc[r * PP + key] += p;
+                }
             }
 #pragma unroll
             for (int e = 0; e < 16; e++)
@@ -424,6 +449,7 @@ template <int DH> __global__ __launch_bounds__(256, 1) void vit_attn_tiled_kerne
         }
         // the next head writes ml before its first barrier and xb after its second: no barrier needed here
     }
+    if constexpr (GACC) return;
     __syncthreads();
     const float nh = (float)a.heads;
     for (int i = tid; i < 32 * N; i += 256) {
@@ -577,7 +603,7 @@ extern "C" int dig_vit_attn(const dig_vit_attn_args* a, void* stream_) {
     DIG_CHECK(a && a->qkv && a->out && a->acc_all, DIG_EINVAL, "vit_attn: null pointer");
     DIG_CHECK(a->B > 0 && a->N > 0 && a->heads > 0 && (a->dh == 64 || a->dh == 32), DIG_EINVAL, "vit_attn: bad shape (head dim must be 32 or 64)");
     const bool no_mfma = getenv("DIG_VIT_ATTN_NO_MFMA") != nullptr;      // test hooks, read per call: keep the VALU kernel,
-    const bool force_tiled = getenv("DIG_VIT_ATTN_TILED") != nullptr;  // or the long-sequence kernel at any N
+    const bool force_tiled = getenv("DIG_VIT_ATTN_TILED") != nullptr || getenv("DIG_VIT_ATTN_GACC") != nullptr;  // or the long-sequence kernel at any N
     if (a->N <= 8 * ATT_MAXE && !no_mfma && !force_tiled) {
         const int NP = (a->N + 31) / 32 * 32 + 4;
         size_t vsz = (size_t)(NP - 4) * (a->dh + 1);  // V rows; reused as the 4 x [32][33] partial-sum exchange of P V
@@ -596,18 +622,22 @@ extern "C" int dig_vit_attn(const dig_vit_attn_args* a, void* stream_) {
         DIG_LAUNCH_CHECK("vit_attn");
         return DIG_OK;
     }
-    if (a->N <= ATT_T_MAXN && !no_mfma) {
+    if (!no_mfma) {  // key-tiled matrix-core kernel; above ATT_T_MAXN tokens the head-sum goes straight to acc_all (GACC)
         const int DT = a->dh / 32;
-        const size_t ldst = ((size_t)32 * (a->N | 1) + 4 * DT * 32 * 33 + 8 * 32 * 2 + 32 * 2) * sizeof(float);
+        const bool gacc = a->N > ATT_T_MAXN || getenv("DIG_VIT_ATTN_GACC") != nullptr;  // (test hook: GACC at any N)
+        const size_t ldst = ((gacc ? 0 : (size_t)32 * (a->N | 1)) + 4 * DT * 32 * 33 + 8 * 32 * 2 + 32 * 2) * sizeof(float);
         const dim3 gridt(cdiv(a->N, TQM), a->B);
         hipError_t e = hipSuccess;
-        if (a->dh == 64) {
-            e = hipFuncSetAttribute((const void*)vit_attn_tiled_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst);
-            if (e == hipSuccess) hipLaunchKernelGGL(vit_attn_tiled_kernel<64>, gridt, dim3(256), ldst, stream, *a);
-        } else {
-            e = hipFuncSetAttribute((const void*)vit_attn_tiled_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst);
-            if (e == hipSuccess) hipLaunchKernelGGL(vit_attn_tiled_kernel<32>, gridt, dim3(256), ldst, stream, *a);
-        }
+#define VIT_TILED_LAUNCH(DHV, G)                                                                                                          \
+    do {                                                                                                                                 \
+        e = hipFuncSetAttribute((const void*)vit_attn_tiled_kernel<DHV, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst);       \
+        if (e == hipSuccess) hipLaunchKernelGGL((vit_attn_tiled_kernel<DHV, G>), gridt, dim3(256), ldst, stream, *a);                    \
+    } while (0)
+        if (a->dh == 64 && gacc) VIT_TILED_LAUNCH(64, true);
+        else if (a->dh == 64) VIT_TILED_LAUNCH(64, false);
+        else if (gacc) VIT_TILED_LAUNCH(32, true);
+        else VIT_TILED_LAUNCH(32, false);
+#undef VIT_TILED_LAUNCH
         DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "vit_attn: cannot raise dynamic LDS to %zu: %s", ldst, hipGetErrorString(e));
         DIG_LAUNCH_CHECK("vit_attn");
         return DIG_OK;

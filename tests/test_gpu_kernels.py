@@ -445,13 +445,15 @@ def test_lfca_helper_kernels(dt):
 @pytest.mark.parametrize("cfg", [(2, 36, 3, 64, ""), (1, 216, 6, 64, ""), (2, 100, 2, 32, ""), (1, 330, 2, 64, ""), (3, 7, 1, 32, ""),
                                  (1, 733, 6, 64, ""), (2, 520, 3, 32, ""), (1, 928, 1, 64, ""), (1, 940, 1, 32, ""),
                                  (2, 36, 3, 64, "TILED"), (3, 7, 1, 32, "TILED"), (1, 97, 2, 64, "TILED"), (1, 128, 2, 32, "TILED"),
-                                 (1, 330, 2, 64, "NO_MFMA")])
+                                 (1, 330, 2, 64, "NO_MFMA"), (2, 36, 3, 64, "GACC"), (1, 733, 6, 64, "GACC"), (1, 97, 2, 32, "GACC"),
+                                 (1, 1573, 6, 64, ""), (1, 2872, 2, 64, "")])
 def test_vit_attn_rollout(cfg, monkeypatch):
     """dig_vit_attn (vision_transformer.py:87-103 + the head-mean / layer-sum of mctformer.py:302-315): output tokens and the
     two probability accumulators against torch, over two layers.  N <= 320 runs on the register-resident fp32 matrix-core
-    kernel, 320 < N <= 928 (733 = the reference's 368x496 VOC crop with 20 class tokens) on the key-tiled one, beyond that the
-    VALU kernel; ragged token counts, both head widths; the env hooks force the tiled / VALU kernels at small N (fewer key
-    tiles than waves, a last tile with one key)."""
+    kernel, 320 < N <= 928 (733 = the reference's 368x496 VOC crop with 20 class tokens) on the key-tiled one with the head-sum
+    in LDS, beyond that (1573 / 2872 = the same crop at scales 1.5 / 2.0 of VOC12DatasetMS) on the key-tiled one that adds
+    p / heads straight into the accumulators (GACC); ragged token counts, both head widths; the env hooks force the tiled /
+    GACC / VALU kernels at small N (fewer key tiles than waves, a last tile with one key)."""
     B, N, heads, dh, hook = cfg
     if hook:
         monkeypatch.setenv("DIG_VIT_ATTN_" + hook, "1")
