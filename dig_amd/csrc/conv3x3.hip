@@ -370,8 +370,8 @@ void conv_config(int Cout, int dtype, int* BN, int* KC, int* TH) {
 }  // namespace
 
 extern "C" int dig_conv3x3_tiles(int H, int W, int C0, int C1, int Cout, int groups, int dtype) {
-    if (conv3x3_ws64_eligible(H, W, C0, C1, Cout, groups, dtype)) return (H / 16) * (W / 16) * 4;  // per-wave partials
     if (conv3x3_db_eligible(C0, C1, Cout, dtype)) return cdiv(H, 16) * cdiv(W, TILE_W);  // one partial per 16x16 pixels from either tile height
+    if (conv3x3_ws64_eligible(H, W, C0, C1, Cout, groups, dtype)) return (H / 16) * (W / 16) * 4;  // per-wave partials
     int BN, KC, TH;
     conv_config(Cout, dtype, &BN, &KC, &TH);
     return cdiv(H, TH) * cdiv(W, TILE_W);
@@ -406,9 +406,10 @@ extern "C" int dig_conv3x3(const dig_conv3x3_args* a, void* stream_) {
         DIG_CHECK(cpg <= BN && BN % cpg == 0 && a->Cout % cpg == 0, DIG_EINVAL,
                   "conv3x3: GroupNorm group width %d does not tile the %d-channel block", cpg, BN);
     }
+    // (the packed weight layout follows the same order: dig_conv3x3_wlayout)
+    if (conv3x3_db_eligible(a->C0, a->in1 ? a->C1 : 0, a->Cout, a->dtype)) return conv3x3_db_launch(a, stream);
     if (conv3x3_ws64_eligible(a->H, a->W, a->C0, a->in1 ? a->C1 : 0, a->Cout, a->stats ? a->groups : 8, a->dtype))
         return conv3x3_ws64_launch(a, stream);
-    if (conv3x3_db_eligible(a->C0, a->in1 ? a->C1 : 0, a->Cout, a->dtype)) return conv3x3_db_launch(a, stream);
     // 128 -> 64 without a GroupNorm prologue: register-stationary weights (same GroupNorm partial count as the generic kernel)
     if (conv3x3_rs128_eligible(a->H, a->W, a->C0, a->in1 ? a->C1 : 0, a->Cout, a->stats ? a->groups : 8, a->dtype, a->aff0 != nullptr) &&
         !getenv("DIG_NO_RS128"))

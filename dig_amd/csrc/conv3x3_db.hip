@@ -35,10 +35,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BN = 128, KC = 16, HALO_W = 18;
-constexpr int WMAIN_BYTES = 4 * BN * 64;                // 32768: taps 0..7 of one chunk = 4 K steps
-constexpr int W8_BYTES = BN * 64;                       // 8192: tap 8 of a chunk pair = 1 K step
-constexpr int PAIR_BYTES = 2 * WMAIN_BYTES + W8_BYTES;  // 73728 = 2 chunks x 9 taps x 128 x 16 x 2 B
+constexpr int KC = 16, HALO_W = 18;
 
 // NW = waves per block = 4-row pixel groups per tile: 8 (32x16-pixel tile, the default) or 4 (16x16-pixel tile, for launches
 // whose 32-row tiles would leave CUs idle: e.g. 256->256 at 32x32 with B = 32 is 128 blocks of 8 waves or 256 of 4).
@@ -46,15 +43,21 @@ constexpr int PAIR_BYTES = 2 * WMAIN_BYTES + W8_BYTES;  // 73728 = 2 chunks x 9 
 // consecutive 16-byte slots, so the bank swizzle is applied on the SOURCE side: slot (pixel, h) holds channel half
 // h ^ (halo row & 1).  A fragment is 16 pixels of ONE row x 2 halves x 2 taps; the 16 lanes that ds_read_b128 serves together
 // read 8 consecutive pixels' one half and the other 8 pixels' other half: all 64 banks.
-template <int NW> struct DbCfg {
+// BN = output channels per block: 128, or 64 for the 64-channel layers (Cout == 64: half the weight slabs, 16 accumulator tiles
+// per wave, two 4-wave blocks per CU at 16-row tiles).
+template <int NW, int BN = 128> struct DbCfg {
+    static constexpr int WMAIN_BYTES = 4 * BN * 64;                // BN=128: 32768: taps 0..7 of one chunk = 4 K steps
+    static constexpr int W8_BYTES = BN * 64;                       // 8192: tap 8 of a chunk pair = 1 K step
+    static constexpr int PAIR_BYTES = 2 * WMAIN_BYTES + W8_BYTES;  // 73728 = 2 chunks x 9 taps x 128 x 16 x 2 B
     static constexpr int TILE_H = 4 * NW, HALO_H = TILE_H + 2, NTHREADS = 64 * NW;
     static constexpr int HSLOTS = HALO_H * HALO_W * 2, HPIECES = (HSLOTS + 63) / 64;  // 16-byte slots, 1 KB DMA pieces
     static constexpr int HALO_BYTES = HPIECES * 1024;                                 // NW=8: 20480, NW=4: 11264
     static constexpr int W_OFF = 3 * HALO_BYTES;                                      // ring of three halo chunks, then the weights
     static constexpr int AFF_OFF = W_OFF + 2 * WMAIN_BYTES + 2 * W8_BYTES;            // NW=8: 143360, NW=4: 115712
-    static constexpr int AFF_MAX_C = 2048;                                            // PRO: [C0][2] fp32 GroupNorm affine of this image
-    static constexpr int DB_LDS = AFF_OFF;
-    static constexpr int DB_LDS_PRO = AFF_OFF + AFF_MAX_C * 8;                        // NW=8: 159744 of 163840
+    static constexpr int AFF_MAX_C = BN == 128 ? 2048 : 256;                          // PRO: [C0][2] fp32 GroupNorm affine of this image
+    static constexpr int EPI_BYTES = NW * 64 * (2 * BN + 16) + NW * (BN / 8) * 8;     // epilogue: staged bf16 rows + GroupNorm sums
+    static constexpr int DB_LDS = AFF_OFF > EPI_BYTES ? AFF_OFF : EPI_BYTES;
+    static constexpr int DB_LDS_PRO = DB_LDS + AFF_MAX_C * 8;                         // NW=8, BN=128: 159744 of 163840
 };
 
 struct DbParams {
@@ -78,8 +81,10 @@ __device__ __forceinline__ f32x4 mma32(const bf16x8& a, const bf16x8& b, const f
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int NW, bool PRO> __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(DbParams p) {
-    using Cfg = DbCfg<NW>;
+template <int NW, bool PRO, int BN> __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(DbParams p) {
+    using Cfg = DbCfg<NW, BN>;
+    constexpr int WMAIN_BYTES = Cfg::WMAIN_BYTES, W8_BYTES = Cfg::W8_BYTES, PAIR_BYTES = Cfg::PAIR_BYTES;
+    constexpr int MT = BN / 16, NG = MT / 2, NJ = BN / 32;  // 16-channel accumulator tiles, fragment groups per K step, 32-channel tile pairs
     constexpr int TILE_H = Cfg::TILE_H, HALO_H = Cfg::HALO_H, NTHREADS = Cfg::NTHREADS;
     constexpr int HALO_BYTES = Cfg::HALO_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -95,9 +100,9 @@ template <int NW, bool PRO> __global__ __launch_bounds__(64 * NW, 2) void conv3x
     const int nch0 = p.C[0] / KC, nch1 = p.C[1] / KC, nch = nch0 + nch1;
     const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w) + (size_t)blockIdx.y * ((nch + 1) >> 1) * PAIR_BYTES;
 
-    f32x4 acc[8][4];  // [channel tile mt][pixel row mr]
+    f32x4 acc[MT][4];  // [channel tile mt][pixel row mr]
 #pragma unroll
-    for (int i = 0; i < 32; i++) acc[i >> 2][i & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MT * 4; i++) acc[i >> 2][i & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- fragment addresses (bytes).  Weights: row `col` of a 16-row tile, slot g swizzled (see the header).
     const int woff = col * 64 + ((g ^ ((0x1320 >> (4 * (col >> 2))) & 3)) << 4);
@@ -238,8 +243,8 @@ template <int NW, bool PRO> __global__ __launch_bounds__(64 * NW, 2) void conv3x
 #pragma unroll
         for (int q = 0; q < 4; q++) {
 #pragma unroll
-            for (int gq = 0; gq < 4; gq++) {
-                if (gq < 3) {
+            for (int gq = 0; gq < NG; gq++) {
+                if (gq < NG - 1) {
                     LA(fa[(gq + 1) & 1], wm + q * (BN * 64), gq + 1);
                 } else if (q < 3) {
                     LA(fa[0], wm + (q + 1) * (BN * 64), 0);
@@ -259,10 +264,11 @@ template <int NW, bool PRO> __global__ __launch_bounds__(64 * NW, 2) void conv3x
                 // the prologue of the NEXT chunk, one DMA piece per MFMA group, late in the period (the pieces were issued at its
                 // start); the two wave halves do it in different K steps so that they do not all leave the matrix pipe at once
                 if constexpr (PRO) {
-                    if (q == (wave < NW / 2 ? 3 : 2) && gq < HPW && more && ci + 1 < nch0) {
+                    if (q == (wave < NW / 2 ? 3 : 2) && more && ci + 1 < nch0) {
                         __builtin_amdgcn_sched_barrier(0);
                         if (gq == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        hpro(ci + 1, hnext, gq);
+#pragma unroll
+                        for (int i = gq; i < HPW; i += NG) hpro(ci + 1, hnext, i);  // the pieces dealt out over the step's groups
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -274,8 +280,8 @@ template <int NW, bool PRO> __global__ __launch_bounds__(64 * NW, 2) void conv3x
                 for (int mr = 0; mr < 4; mr++) fb[0][mr] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             }
 #pragma unroll
-            for (int gq = 0; gq < 4; gq++) {
-                if (gq < 3) LA(fa[(gq + 1) & 1], w8, gq + 1);
+            for (int gq = 0; gq < NG; gq++) {
+                if (gq < NG - 1) LA(fa[(gq + 1) & 1], w8, gq + 1);
                 DB_FENCE;
                 MM(fa[gq & 1], fb[0], gq);
                 DB_FENCE;
@@ -295,9 +301,9 @@ template <int NW, bool PRO> __global__ __launch_bounds__(64 * NW, 2) void conv3x
     // OWN 64 x 272-byte LDS rows (no block barrier: every wave is past the loop's last one) and leave as whole 256-byte pixel rows.
     constexpr int EROW = 2 * BN + 16;  // bytes per staged pixel (+16: the 8 lanes that ds_write_b128 serves together hit 8 bank groups)
     unsigned char* const est = smem + wave * (64 * EROW);
-    float cs[4], css[4];
+    float cs[NJ], css[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < NJ; j++) {
         cs[j] = css[j] = 0.f;
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 32 * j + 8 * g), b1 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 32 * j + 8 * g + 4);
 #pragma unroll
@@ -323,38 +329,30 @@ template <int NW, bool PRO> __global__ __launch_bounds__(64 * NW, 2) void conv3x
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#ifndef DB_NOSTORE
 #pragma unroll
-    for (int i = 0; i < 16; i++) {  // 4 pixels x 256 bytes per wave instruction
-        const int pix = i * 4 + (lane >> 4), v16 = lane & 15;
+    for (int i = 0; i < BN / 8; i++) {  // (512 / BN) pixels x 2*BN bytes per wave instruction
+        constexpr int VPP = BN / 8, PPI = 64 / VPP;  // 16-byte vectors per pixel, pixels per instruction
+        const int pix = i * PPI + lane / VPP, v16 = lane % VPP;
         const int Y = ty0 + 4 * pg + (pix >> 4), X = tx0 + (pix & 15);
         if (Y < p.H && X < p.W)
-        {
-            const bf16x8 ov = *reinterpret_cast<const bf16x8*>(est + pix * EROW + v16 * 16);
-            bf16x8* op = reinterpret_cast<bf16x8*>(p.out + (((size_t)b * p.H + Y) * p.W + X) * p.Cout + n0 + v16 * 8);
-#ifdef DB_NT_STORE
-            __builtin_nontemporal_store(ov, op);
-#else
-            *op = ov;
-#endif
-        }
+            *reinterpret_cast<bf16x8*>(p.out + (((size_t)b * p.H + Y) * p.W + X) * p.Cout + n0 + v16 * 8) = *reinterpret_cast<const bf16x8*>(est + pix * EROW + v16 * 16);
     }
-#endif
     if (p.stats != nullptr) {
         // per wave and 8-channel vector (j, g): sums over the wave's 4 x 16 pixels (xor tree over the 16 pixel columns), then
         // - fixed order, so deterministic - over the 4 waves of a 16-row sub-tile and the vectors of a GroupNorm group.  One
         // partial per 16x16 pixels from either tile height, summed the same way: the launch heuristic cannot change a bit.
-        float* st = reinterpret_cast<float*>(smem + NW * (64 * EROW));  // [wave][16 vectors][2], behind the staging rows
+        constexpr int NV = BN / 8;  // 8-channel vectors of the N tile
+        float* st = reinterpret_cast<float*>(smem + NW * (64 * EROW));  // [wave][NV vectors][2], behind the staging rows
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < NJ; j++) {
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) {
                 cs[j] += __shfl_xor(cs[j], o, 64);
                 css[j] += __shfl_xor(css[j], o, 64);
             }
             if (col == 0) {
-                st[((pg * 16) + j * 4 + g) * 2] = cs[j];
-                st[((pg * 16) + j * 4 + g) * 2 + 1] = css[j];
+                st[((pg * NV) + j * 4 + g) * 2] = cs[j];
+                st[((pg * NV) + j * 4 + g) * 2 + 1] = css[j];
             }
         }
         __syncthreads();
@@ -370,8 +368,8 @@ template <int NW, bool PRO> __global__ __launch_bounds__(64 * NW, 2) void conv3x
                 float s = 0.f, ss = 0.f;
                 for (int k = 0; k < 4; k++)
                     for (int v = 0; v < vpg; v++) {
-                        s += st[(((ns * 4 + k) * 16) + gi * vpg + v) * 2];
-                        ss += st[(((ns * 4 + k) * 16) + gi * vpg + v) * 2 + 1];
+                        s += st[(((ns * 4 + k) * NV) + gi * vpg + v) * 2];
+                        ss += st[(((ns * 4 + k) * NV) + gi * vpg + v) * 2 + 1];
                     }
                 float* dst = p.stats + (((size_t)b * p.groups + grp) * (rows16 * p.tiles_x) + ty16 * p.tiles_x + (tile % p.tiles_x)) * 2;
                 dst[0] = s;
@@ -383,12 +381,28 @@ template <int NW, bool PRO> __global__ __launch_bounds__(64 * NW, 2) void conv3x
 
 }  // namespace
 
-// eligibility: bf16, whole 128-channel output tiles, 16-channel input chunks
+// eligibility: bf16, 16-channel input chunks, and either whole 128-channel output tiles or the 64-channel layers this kernel
+// is the faster one for (db64_wanted)
+// Measured at B = 32, 256x256 (tools/lab/ab_env.sh): the BN = 64 instantiation loses to both special kernels of the 64-channel
+// layers - 128 -> 64: 340 us against 318 (conv3x3_rs128), 64 -> 64: 222 / 280 us (plain / prologue) against 160 / 206
+// (conv3x3_ws64): with 4-8 chunks per tile the per-tile weight re-fetch and fill are not amortised.  It therefore stays OFF by
+// default and exists for Cout = 64 shapes the special kernels do not take.  DIG_DB64 (read per call: the weight packer asks
+// dig_conv3x3_wlayout with the same setting) = "all": every Cout == 64 layer, "k128": the 128 -> 64 layers, default none.
+static int db64_mode() {
+    const char* e = getenv("DIG_DB64");
+    if (!e) return 0;
+    return e[0] == 'a' ? 2 : (e[0] == 'k' ? 1 : 0);
+}
+static bool db64_wanted(int C0, int C1) {
+    const int m = db64_mode();
+    return m == 2 || (m == 1 && C0 + C1 == 128);
+}
 bool conv3x3_db_eligible(int C0, int C1, int Cout, int dtype) {
-    return dtype == DIG_BF16 && Cout % 128 == 0 && C0 % 16 == 0 && C1 % 16 == 0;
+    if (dtype != DIG_BF16 || C0 % 16 != 0 || C1 % 16 != 0) return false;
+    return Cout % 128 == 0 || (Cout == 64 && db64_wanted(C0, C1));
 }
 
-int conv3x3_db_launch(const dig_conv3x3_args* a, hipStream_t stream) {
+template <int BN> static int db_launch(const dig_conv3x3_args* a, hipStream_t stream) {
     DbParams p;
     p.in[0] = (const bf16*)a->in0;
     p.in[1] = (const bf16*)a->in1;
@@ -404,39 +418,46 @@ int conv3x3_db_launch(const dig_conv3x3_args* a, hipStream_t stream) {
     p.tiles_x = cdiv(a->W, 16);
     if (a->stats) {
         const int cpg = a->Cout / a->groups;
-        DIG_CHECK(cpg % 8 == 0, DIG_EINVAL, "conv3x3(db): GroupNorm group width %d must be a multiple of 8", cpg);
+        DIG_CHECK(cpg % 8 == 0 && BN % cpg == 0, DIG_EINVAL, "conv3x3(db): GroupNorm group width %d must be a multiple of 8 that divides %d", cpg, BN);
     }
     DIG_CHECK(((uintptr_t)a->bias) % 16 == 0, DIG_EALIGN, "conv3x3(db): bias must be 16-byte aligned");
-    static std::atomic<int> ncu[64];  // zero-initialised; racing first calls all store the same values
+    static std::atomic<int> ncu[64];  // zero-initialised; racing first calls all store the same values (one set per BN)
     int device = 0;
     (void)hipGetDevice(&device);
     const int dev = device & 63;
     int ncus = ncu[dev].load(std::memory_order_acquire);
     if (!ncus) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<8>::DB_LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<4>::DB_LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<8>::DB_LDS_PRO);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<4>::DB_LDS_PRO);
-        DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "conv3x3(db): cannot raise dynamic LDS to %d: %s", DbCfg<8>::DB_LDS, hipGetErrorString(e));
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<8, false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<8, BN>::DB_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<4, false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<4, BN>::DB_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<8, true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<8, BN>::DB_LDS_PRO);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<4, true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<4, BN>::DB_LDS_PRO);
+        DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "conv3x3(db): cannot raise dynamic LDS to %d: %s", DbCfg<8, BN>::DB_LDS_PRO, hipGetErrorString(e));
         int n = 0;
         e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device);
         DIG_CHECK(e == hipSuccess && n > 0, DIG_ELAUNCH, "conv3x3(db): cannot query the CU count");
         ncu[dev].store(n, std::memory_order_release);
         ncus = n;
     }
-    // 32-row tiles unless they would leave CUs without a block (one block per CU: 140 KB of LDS); then 16-row tiles, 4 waves
+    // BN = 128: 32-row tiles unless they would leave CUs without a block (one block per CU: 140 KB of LDS); then 16-row tiles,
+    // 4 waves.  BN = 64: 16-row tiles, two 4-wave blocks per CU (75 KB each) - a tile has few chunks (4 or 8), and the second
+    // block's main loop covers the first one's fill and epilogue.
     const long long grid32 = (long long)a->B * p.tiles_x * cdiv(a->H, 32) * (a->Cout / BN);
     const char* force = getenv("DIG_DB_TILE");  // test hook, read per call (the tests flip it inside one process): "16" / "32"
-    const bool small = force ? atoi(force) == 16 : grid32 < ncus;
+    const bool small = force ? atoi(force) == 16 : (BN == 64 || grid32 < ncus);
     const bool pro = a->aff0 != nullptr;  // GroupNorm-apply + SiLU prologue on the channels of in0
-    DIG_CHECK(!pro || (a->C0 <= DbCfg<8>::AFF_MAX_C && ((uintptr_t)a->aff0) % 16 == 0), DIG_EINVAL,
-              "conv3x3(db): a prologue needs C0 <= %d and a 16-byte aligned aff0 (C0 = %d)", DbCfg<8>::AFF_MAX_C, a->C0);
+    DIG_CHECK(!pro || (a->C0 <= DbCfg<8, BN>::AFF_MAX_C && ((uintptr_t)a->aff0) % 16 == 0), DIG_EINVAL,
+              "conv3x3(db): a prologue needs C0 <= %d and a 16-byte aligned aff0 (C0 = %d)", DbCfg<8, BN>::AFF_MAX_C, a->C0);
     p.tiles_y = cdiv(a->H, small ? 16 : 32);
     const dim3 grid(a->B * p.tiles_x * p.tiles_y, a->Cout / BN);
-    if (small && pro) hipLaunchKernelGGL((conv3x3_db_kernel<4, true>), grid, dim3(256), DbCfg<4>::DB_LDS_PRO, stream, p);
-    else if (small) hipLaunchKernelGGL((conv3x3_db_kernel<4, false>), grid, dim3(256), DbCfg<4>::DB_LDS, stream, p);
-    else if (pro) hipLaunchKernelGGL((conv3x3_db_kernel<8, true>), grid, dim3(512), DbCfg<8>::DB_LDS_PRO, stream, p);
-    else hipLaunchKernelGGL((conv3x3_db_kernel<8, false>), grid, dim3(512), DbCfg<8>::DB_LDS, stream, p);
+    constexpr int lds4 = DbCfg<4, BN>::DB_LDS, lds4p = DbCfg<4, BN>::DB_LDS_PRO, lds8 = DbCfg<8, BN>::DB_LDS, lds8p = DbCfg<8, BN>::DB_LDS_PRO;
+    if (small && pro) hipLaunchKernelGGL((conv3x3_db_kernel<4, true, BN>), grid, dim3(256), lds4p, stream, p);
+    else if (small) hipLaunchKernelGGL((conv3x3_db_kernel<4, false, BN>), grid, dim3(256), lds4, stream, p);
+    else if (pro) hipLaunchKernelGGL((conv3x3_db_kernel<8, true, BN>), grid, dim3(512), lds8p, stream, p);
+    else hipLaunchKernelGGL((conv3x3_db_kernel<8, false, BN>), grid, dim3(512), lds8, stream, p);
     DIG_LAUNCH_CHECK("conv3x3(db)");
     return DIG_OK;
+}
+
+int conv3x3_db_launch(const dig_conv3x3_args* a, hipStream_t stream) {
+    return a->Cout % 128 == 0 ? db_launch<128>(a, stream) : db_launch<64>(a, stream);
 }

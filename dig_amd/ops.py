@@ -57,7 +57,7 @@ def _pack_pairs(w, nt, nch, BN, KC):
       w8(P)  : [128 rows][4 slots][8]               slot s = tap 8 of chunk 2P + (s >> 1), channel half s & 1
     row rho = mt*16 + rr holds output channel 32*(mt >> 1) + 8*(rr >> 2) + 4*(mt & 1) + (rr & 3); slot s sits at position
     s ^ f[(rho >> 2) & 3], f = (0, 2, 3, 1).  An odd chunk count is padded with a zero chunk."""
-    assert BN == 128 and KC == 16
+    assert BN in (64, 128) and KC == 16
     dev = w.device
     npairs = (nch + 1) // 2
     w = torch.nn.functional.pad(w, (0, npairs * 32 - nch * KC))

@@ -110,6 +110,41 @@ def test_conv3x3_double_buffered_variants(cfg):
         assert (nchw(y) - ref).abs().max() <= 2 * tol(dt, ref)
 
 
+@pytest.mark.parametrize("cfg", [(64, 64, 40, 36), (128, 0, 33, 70), (64, 0, 16, 32), (48, 0, 20, 24)])
+def test_conv3x3_db_64_channel_instantiation(cfg, monkeypatch):
+    """The BN = 64 instantiation of conv3x3_db.hip (off by default: the weight-/register-stationary kernels are faster on the
+    Unet's 64-channel layers; DIG_DB64=all routes every Cout = 64 layer to it, weights packed to match): plain, concat,
+    nearest-x2 and prologue launches against F.conv2d, GroupNorm partials, and the same bits from both tile heights."""
+    monkeypatch.setenv("DIG_DB64", "all")
+    C0, C1, H, W = cfg
+    dt, B, Co = torch.bfloat16, 2, 64
+    x0 = q(rnd("d6x0", (B, C0, H, W)), dt)
+    x1 = q(rnd("d6x1", (B, C1, H, W)), dt) if C1 else None
+    w, b = q(rnd("d6w", (Co, C0 + C1, 3, 3), (3.0 / (9 * (C0 + C1))) ** 0.5), dt), rnd("d6b", (Co,), 0.1)
+    ref = F.conv2d(torch.cat([x0, x1], 1) if C1 else x0, w, b, padding=1)
+    cw = ops.ConvWeight(w.to(DEV), b.to(DEV), dt, C1=C1)
+    outs = {}
+    for th in ("16", "32"):
+        monkeypatch.setenv("DIG_DB_TILE", th)
+        y, st = ops.conv3x3(nhwc(x0, dt), cw, x1=nhwc(x1, dt) if C1 else None)
+        assert (nchw(y) - ref).abs().max() <= tol(dt, ref)
+        assert st.shape == (B, 8, ((H + 15) // 16) * ((W + 15) // 16), 2)
+        g = ref.reshape(B, 8, -1).double()
+        assert torch.allclose(st.cpu().double().sum(2)[..., 0], g.sum(-1), rtol=1e-3, atol=1e-2 * g.shape[-1] ** 0.5)
+        outs[th] = [y, st]
+        if C1 == 0:
+            aff = torch.stack([1.0 + 0.3 * rnd("d6a", (B, C0)), 0.2 * rnd("d6ab", (B, C0))], -1)
+            xp = F.silu(x0 * aff[..., 0][:, :, None, None] + aff[..., 1][:, :, None, None])
+            yp, _ = ops.conv3x3(nhwc(x0, dt), cw, aff=aff.to(DEV).contiguous())
+            assert (nchw(yp) - F.conv2d(q(xp, dt), w, b, padding=1)).abs().max() <= 2 * tol(dt, ref)
+            xs = x0[:, :, : H // 2, : W // 2].contiguous()
+            yu, _ = ops.conv3x3(nhwc(xs, dt), cw, up2=True, want_stats=False)
+            assert (nchw(yu) - F.conv2d(F.interpolate(xs, scale_factor=2, mode="nearest"), w, b, padding=1)).abs().max() <= tol(dt, ref)
+            outs[th] += [yp, yu]
+    for a_, b_ in zip(outs["16"], outs["32"]):
+        assert torch.equal(a_, b_)
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 128, 32, 32), (1, 32, 256, 48, 40), (3, 48, 128, 16, 16), (2, 32, 128, 20, 33)])
 def test_conv3x3_db_tile_heights_bitwise(shape, monkeypatch):
     """conv3x3_db.hip picks 16-row tiles (4 waves) when 32-row tiles (8 waves) would leave CUs idle, i.e. depending on the
