@@ -13,9 +13,22 @@ __global__ void gn_finalize_kernel(dig_gn_finalize_args a) {
     const int cpg = a.C / a.groups;
     const float* st = a.stats + ((size_t)b * a.groups + g) * a.tiles * 2;
     double s = 0.0, ss = 0.0;
-    for (int i = threadIdx.x; i < a.tiles; i += 64) {
-        s += (double)st[2 * i];
-        ss += (double)st[2 * i + 1];
+    // 8 partials per round trip (all loads issued before the first add; the adds keep their order, so the sums are the same
+    // bits as the plain loop's): at 256x256 the weight-stationary kernel leaves 1024 partials per (image, group)
+    for (int i0 = threadIdx.x; i0 < a.tiles; i0 += 64 * 8) {
+        f32x2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + 64 * u;
+            v[u] = i < a.tiles ? *reinterpret_cast<const f32x2*>(st + 2 * i) : f32x2{0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (i0 + 64 * u < a.tiles) {
+                s += (double)v[u][0];
+                ss += (double)v[u][1];
+            }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
