@@ -26,6 +26,7 @@
 //   four 16-byte slots are stored at position s ^ f[(rho >> 2) & 3], f = {0, 2, 3, 1}: with 64-byte rows that makes the
 //   16-lane groups of ds_read_b128 hit 16 different 16-byte bank groups (MI355X_MICROARCH.md, LDS).
 #include <cstdlib>
+#include <cstring>
 
 #include "common.hpp"
 
@@ -54,7 +55,7 @@ template <int NW, int BN = 128> struct DbCfg {
     static constexpr int HALO_BYTES = HPIECES * 1024;                                 // NW=8: 20480, NW=4: 11264
     static constexpr int W_OFF = 3 * HALO_BYTES;                                      // ring of three halo chunks, then the weights
     static constexpr int AFF_OFF = W_OFF + 2 * WMAIN_BYTES + 2 * W8_BYTES;            // NW=8: 143360, NW=4: 115712
-    static constexpr int AFF_MAX_C = BN == 128 ? 2048 : 256;                          // PRO: [C0][2] fp32 GroupNorm affine of this image
+    static constexpr int AFF_MAX_C = BN == 128 ? 2048 : 768;                          // PRO: [C0][2] fp32 GroupNorm affine of this image (BN = 64, 4 waves: two blocks per CU still fit)
     static constexpr int EPI_BYTES = NW * 64 * (2 * BN + 16) + NW * (BN / 8) * 8;     // epilogue: staged bf16 rows + GroupNorm sums
     static constexpr int DB_LDS = AFF_OFF > EPI_BYTES ? AFF_OFF : EPI_BYTES;
     static constexpr int DB_LDS_PRO = DB_LDS + AFF_MAX_C * 8;                         // NW=8, BN=128: 159744 of 163840
@@ -81,7 +82,9 @@ __device__ __forceinline__ f32x4 mma32(const bf16x8& a, const bf16x8& b, const f
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int NW, bool PRO, int BN> __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(DbParams p) {
+// WP = the N-tile width the weights were PACKED for: BN, or 128 with BN = 64 - then the block takes the lower / upper 64 rows of a
+// 128-row slab (whole 4 KB runs per K step; the row -> channel map and the slot swizzle of rows 64..127 repeat those of 0..63).
+template <int NW, bool PRO, int BN, int WP = BN> __global__ __launch_bounds__(64 * NW, 2) void conv3x3_db_kernel(DbParams p) {
     using Cfg = DbCfg<NW, BN>;
     constexpr int WMAIN_BYTES = Cfg::WMAIN_BYTES, W8_BYTES = Cfg::W8_BYTES, PAIR_BYTES = Cfg::PAIR_BYTES;
     constexpr int MT = BN / 16, NG = MT / 2, NJ = BN / 32;  // 16-channel accumulator tiles, fragment groups per K step, 32-channel tile pairs
@@ -98,7 +101,11 @@ template <int NW, bool PRO, int BN> __global__ __launch_bounds__(64 * NW, 2) voi
     const int n0 = blockIdx.y * BN;
     const int Hs = p.up2 ? p.H >> 1 : p.H, Ws = p.up2 ? p.W >> 1 : p.W;
     const int nch0 = p.C[0] / KC, nch1 = p.C[1] / KC, nch = nch0 + nch1;
-    const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w) + (size_t)blockIdx.y * ((nch + 1) >> 1) * PAIR_BYTES;
+    static_assert(WP == BN || (WP == 128 && BN == 64), "weights packed for BN, or for 128 rows and split in halves");
+    constexpr int SRC_MAIN = 4 * WP * 64, SRC_PAIR = 2 * SRC_MAIN + WP * 64;  // the packed slabs' sizes
+    constexpr int NSPLIT = WP / BN;
+    const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w) + (size_t)(blockIdx.y / NSPLIT) * ((nch + 1) >> 1) * SRC_PAIR +
+                                 (size_t)(blockIdx.y % NSPLIT) * (BN * 64);
 
     f32x4 acc[MT][4];  // [channel tile mt][pixel row mr]
 #pragma unroll
@@ -176,16 +183,17 @@ template <int NW, bool PRO, int BN> __global__ __launch_bounds__(64 * NW, 2) voi
     // global -> LDS directly, piece q by wave q % NW
     unsigned char* const wl = smem + Cfg::W_OFF;
     auto wload = [&](int ci) {
-        const unsigned char* pair = wbase + (size_t)(ci >> 1) * PAIR_BYTES;
-        const unsigned char* slab = pair + (ci & 1) * WMAIN_BYTES;
+        const unsigned char* pair = wbase + (size_t)(ci >> 1) * SRC_PAIR;
+        const unsigned char* slab = pair + (ci & 1) * SRC_MAIN;
         unsigned char* dst = wl + (ci & 1) * WMAIN_BYTES;
+        constexpr int PPS = BN * 64 / 1024;  // 1 KB pieces per K step of this block's rows
 #ifdef DB_DMA_UNROLL1
 #pragma unroll 1
 #endif
         for (int q = wave; q < WMAIN_BYTES / 1024; q += NW)
-            __builtin_amdgcn_global_load_lds((glb_void*)(slab + q * 1024 + lane * 16), (lds_void*)(dst + q * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(slab + (q / PPS) * (WP * 64) + (q % PPS) * 1024 + lane * 16), (lds_void*)(dst + q * 1024), 16, 0, 0);
         if (!(ci & 1)) {
-            const unsigned char* s8 = pair + 2 * WMAIN_BYTES;
+            const unsigned char* s8 = pair + 2 * SRC_MAIN;
             unsigned char* d8 = wl + 2 * WMAIN_BYTES + ((ci >> 1) & 1) * W8_BYTES;
 #ifdef DB_DMA_UNROLL1
 #pragma unroll 1
@@ -402,7 +410,8 @@ bool conv3x3_db_eligible(int C0, int C1, int Cout, int dtype) {
     return Cout % 128 == 0 || (Cout == 64 && db64_wanted(C0, C1));
 }
 
-template <int BN> static int db_launch(const dig_conv3x3_args* a, hipStream_t stream) {
+// BN = channels per block, WP = the N-tile width the weights are packed for (conv_config: 128 when Cout % 128 == 0, else 64)
+template <int BN, int WP> static int db_launch(const dig_conv3x3_args* a, hipStream_t stream, bool small, bool pro) {
     DbParams p;
     p.in[0] = (const bf16*)a->in0;
     p.in[1] = (const bf16*)a->in1;
@@ -420,44 +429,73 @@ template <int BN> static int db_launch(const dig_conv3x3_args* a, hipStream_t st
         const int cpg = a->Cout / a->groups;
         DIG_CHECK(cpg % 8 == 0 && BN % cpg == 0, DIG_EINVAL, "conv3x3(db): GroupNorm group width %d must be a multiple of 8 that divides %d", cpg, BN);
     }
-    DIG_CHECK(((uintptr_t)a->bias) % 16 == 0, DIG_EALIGN, "conv3x3(db): bias must be 16-byte aligned");
-    static std::atomic<int> ncu[64];  // zero-initialised; racing first calls all store the same values (one set per BN)
+    static std::atomic<bool> attr_set[64];  // per instantiation (BN, WP) and device; racing first calls all do the same
     int device = 0;
     (void)hipGetDevice(&device);
     const int dev = device & 63;
-    int ncus = ncu[dev].load(std::memory_order_acquire);
-    if (!ncus) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<8, false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<8, BN>::DB_LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<4, false, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<4, BN>::DB_LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<8, true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<8, BN>::DB_LDS_PRO);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<4, true, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<4, BN>::DB_LDS_PRO);
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<8, false, BN, WP>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<8, BN>::DB_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<4, false, BN, WP>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<4, BN>::DB_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<8, true, BN, WP>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<8, BN>::DB_LDS_PRO);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_db_kernel<4, true, BN, WP>, hipFuncAttributeMaxDynamicSharedMemorySize, DbCfg<4, BN>::DB_LDS_PRO);
         DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "conv3x3(db): cannot raise dynamic LDS to %d: %s", DbCfg<8, BN>::DB_LDS_PRO, hipGetErrorString(e));
-        int n = 0;
-        e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device);
-        DIG_CHECK(e == hipSuccess && n > 0, DIG_ELAUNCH, "conv3x3(db): cannot query the CU count");
-        ncu[dev].store(n, std::memory_order_release);
-        ncus = n;
+        attr_set[dev].store(true, std::memory_order_release);
     }
-    // BN = 128: 32-row tiles unless they would leave CUs without a block (one block per CU: 140 KB of LDS); then 16-row tiles,
-    // 4 waves.  BN = 64: 16-row tiles, two 4-wave blocks per CU (75 KB each) - a tile has few chunks (4 or 8), and the second
-    // block's main loop covers the first one's fill and epilogue.
-    const long long grid32 = (long long)a->B * p.tiles_x * cdiv(a->H, 32) * (a->Cout / BN);
-    const char* force = getenv("DIG_DB_TILE");  // test hook, read per call (the tests flip it inside one process): "16" / "32"
-    const bool small = force ? atoi(force) == 16 : (BN == 64 || grid32 < ncus);
-    const bool pro = a->aff0 != nullptr;  // GroupNorm-apply + SiLU prologue on the channels of in0
     DIG_CHECK(!pro || (a->C0 <= DbCfg<8, BN>::AFF_MAX_C && ((uintptr_t)a->aff0) % 16 == 0), DIG_EINVAL,
               "conv3x3(db): a prologue needs C0 <= %d and a 16-byte aligned aff0 (C0 = %d)", DbCfg<8, BN>::AFF_MAX_C, a->C0);
     p.tiles_y = cdiv(a->H, small ? 16 : 32);
     const dim3 grid(a->B * p.tiles_x * p.tiles_y, a->Cout / BN);
     constexpr int lds4 = DbCfg<4, BN>::DB_LDS, lds4p = DbCfg<4, BN>::DB_LDS_PRO, lds8 = DbCfg<8, BN>::DB_LDS, lds8p = DbCfg<8, BN>::DB_LDS_PRO;
-    if (small && pro) hipLaunchKernelGGL((conv3x3_db_kernel<4, true, BN>), grid, dim3(256), lds4p, stream, p);
-    else if (small) hipLaunchKernelGGL((conv3x3_db_kernel<4, false, BN>), grid, dim3(256), lds4, stream, p);
-    else if (pro) hipLaunchKernelGGL((conv3x3_db_kernel<8, true, BN>), grid, dim3(512), lds8p, stream, p);
-    else hipLaunchKernelGGL((conv3x3_db_kernel<8, false, BN>), grid, dim3(512), lds8, stream, p);
+    if (small && pro) hipLaunchKernelGGL((conv3x3_db_kernel<4, true, BN, WP>), grid, dim3(256), lds4p, stream, p);
+    else if (small) hipLaunchKernelGGL((conv3x3_db_kernel<4, false, BN, WP>), grid, dim3(256), lds4, stream, p);
+    else if (pro) hipLaunchKernelGGL((conv3x3_db_kernel<8, true, BN, WP>), grid, dim3(512), lds8p, stream, p);
+    else hipLaunchKernelGGL((conv3x3_db_kernel<8, false, BN, WP>), grid, dim3(512), lds8, stream, p);
     DIG_LAUNCH_CHECK("conv3x3(db)");
     return DIG_OK;
 }
 
 int conv3x3_db_launch(const dig_conv3x3_args* a, hipStream_t stream) {
-    return a->Cout % 128 == 0 ? db_launch<128>(a, stream) : db_launch<64>(a, stream);
+    DIG_CHECK(((uintptr_t)a->bias) % 16 == 0, DIG_EALIGN, "conv3x3(db): bias must be 16-byte aligned");
+    static std::atomic<int> ncu[64];  // zero-initialised; racing first calls all store the same value
+    int device = 0;
+    (void)hipGetDevice(&device);
+    int ncus = ncu[device & 63].load(std::memory_order_acquire);
+    if (!ncus) {
+        hipError_t e = hipDeviceGetAttribute(&ncus, hipDeviceAttributeMultiprocessorCount, device);
+        DIG_CHECK(e == hipSuccess && ncus > 0, DIG_ELAUNCH, "conv3x3(db): cannot query the CU count");
+        ncu[device & 63].store(ncus, std::memory_order_release);
+    }
+    const bool pro = a->aff0 != nullptr;  // GroupNorm-apply + SiLU prologue on the channels of in0
+    const int tx = cdiv(a->W, 16);
+    if (a->Cout % 128 != 0) {  // weights packed per 64 channels: 16-row tiles, two 4-wave blocks per CU (a tile has few chunks,
+                               // and the second block's main loop covers the first one's fill and epilogue)
+        const char* force = getenv("DIG_DB_TILE");
+        return db_launch<64, 64>(a, stream, force ? atoi(force) == 16 : true, pro);
+    }
+    // Block shape (rows x output channels) by a cost model, in units of one 32-row x 128-channel block on a CU of its own:
+    // rounds of blocks x cost per block, the costs measured at B = 32 / 20, 256x256 (tools/lab/ab_shapes.sh; per unit of work a
+    // 16 x 128 block costs 1.25 (1.36 with the prologue, whose SiLU every block repeats on its own halo), a 16 x 64 block 1.12
+    // (1.32): two of those share a CU (75 KB of LDS each), so a full round of 2 x #CUs blocks costs 0.56 (0.66) and a last
+    // round that leaves at most one block per CU 0.38 (0.45)).  The small shapes win where they remove a mostly empty last
+    // round: 20 images at 64x64 with 256 output channels are 320 blocks of 32 x 128 (2 rounds) or 1280 of 16 x 64
+    // (2 x 0.56 + 0.38: measured 165 against 206 us).  EVERY shape gives the same bits - outputs and GroupNorm partials (one
+    // per 16x16 pixels and group, summed in the same order) - so the choice may depend on the batch without breaking the
+    // shard-equals-batch invariance (tests/test_gpu_kernels.py::test_conv3x3_db_tile_heights_bitwise).
+    const long long g32 = (long long)a->B * tx * cdiv(a->H, 32) * (a->Cout / 128), g16 = (long long)a->B * tx * cdiv(a->H, 16) * (a->Cout / 128);
+    const double c32 = (double)((g32 + ncus - 1) / ncus);
+    const double c16 = (pro ? 0.68 : 0.625) * (double)((g16 + ncus - 1) / ncus);
+    const long long gq = 2 * g16, full = gq / (2 * ncus), rem = gq - full * 2 * ncus;
+    const double cq = (pro ? 0.66 : 0.56) * (double)full + (rem == 0 ? 0.0 : (rem <= ncus ? (pro ? 0.45 : 0.38) : (pro ? 0.66 : 0.56)));
+    int shape = c16 < 0.97 * c32 ? 1 : 0;                // 0: 32 x 128, 1: 16 x 128, 2: 16 x 64, 3: 32 x 64 (test hook only)
+    if (cq < 0.97 * (shape ? c16 : c32) && (!a->stats || (64 % (a->Cout / a->groups)) == 0) && (!pro || a->C0 <= DbCfg<4, 64>::AFF_MAX_C)) shape = 2;
+    if (const char* force = getenv("DIG_DB_TILE")) {     // test hook, read per call: "16" / "32" [+ "x64"]
+        shape = (atoi(force) == 16 ? 1 : 0);
+        if (strstr(force, "x64")) shape = shape ? 2 : 3;
+    }
+    switch (shape) {
+        case 0: return db_launch<128, 128>(a, stream, false, pro);
+        case 1: return db_launch<128, 128>(a, stream, true, pro);
+        case 2: return db_launch<64, 128>(a, stream, true, pro);
+        default: return db_launch<64, 128>(a, stream, false, pro);
+    }
 }

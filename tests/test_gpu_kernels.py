@@ -147,8 +147,8 @@ def test_conv3x3_db_64_channel_instantiation(cfg, monkeypatch):
 
 @pytest.mark.parametrize("shape", [(2, 64, 128, 32, 32), (1, 32, 256, 48, 40), (3, 48, 128, 16, 16), (2, 32, 128, 20, 33)])
 def test_conv3x3_db_tile_heights_bitwise(shape, monkeypatch):
-    """conv3x3_db.hip picks 16-row tiles (4 waves) when 32-row tiles (8 waves) would leave CUs idle, i.e. depending on the
-    batch.  Both must give the same bits - outputs AND GroupNorm partials (one per 16x16 pixels from either height) - or a
+    """conv3x3_db.hip picks its block shape - 32 or 16 rows, 128 or 64 output channels - by a cost model of the launch, i.e.
+    depending on the batch.  All must give the same bits - outputs AND GroupNorm partials (one per 16x16 pixels from either height) - or a
     shard of a batch would not be bitwise equal to the same images inside the full batch.  Ragged heights included."""
     B, Cin, Co, H, W = shape
     dt = torch.bfloat16
@@ -157,11 +157,14 @@ def test_conv3x3_db_tile_heights_bitwise(shape, monkeypatch):
     cw = ops.ConvWeight(w.to(DEV), b.to(DEV), dt)
     aff = torch.stack([1.0 + 0.3 * rnd("dbta", (B, Cin)), 0.2 * rnd("dbtbb", (B, Cin))], -1).to(DEV).contiguous()
     outs, up = {}, {}
-    for th in ("16", "32"):
+    for th in ("16", "32", "16x64", "32x64"):  # rows [x output channels per block; default 128]
         monkeypatch.setenv("DIG_DB_TILE", th)
         outs[th] = ops.conv3x3(x, cw), ops.conv3x3(x, cw, aff=aff)
         up[th] = ops.conv3x3(x, cw, up2=True, want_stats=False)[0]  # nearest-x2 source addressing of the halo DMA
-    assert torch.equal(up["16"], up["32"])
+    assert torch.equal(up["16"], up["32"]) and torch.equal(up["16"], up["16x64"]) and torch.equal(up["16"], up["32x64"])
+    for th in ("16x64", "32x64"):  # the half-N-tile blocks (lower / upper 64 rows of the 128-row weight slabs): same bits again
+        for (ya, sa), (yb, sb) in zip(outs["16"], outs[th]):
+            assert torch.equal(ya, yb) and torch.equal(sa, sb), th
     for (y16, s16), (y32, s32) in zip(outs["16"], outs["32"]):
         assert s16.shape == s32.shape == (B, 8, ((H + 15) // 16) * ((W + 15) // 16), 2)
         assert torch.equal(y16, y32) and torch.equal(s16, s32)
