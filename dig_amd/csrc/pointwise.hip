@@ -48,7 +48,10 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void pw_res_kernel(dig_pw_r
     bf16* gs = gs_all + wave * 32 * NP;
     float* aff = aff_l + wave * N * 2;
     const long long nsub = a.M / 32;
-    const long long sub0 = ((long long)blockIdx.x * iters) * 4 + wave;
+    // Sub-tiles are dealt round-robin over the blocks (iteration `it` of block b takes group it * gridDim + b): at any moment the
+    // resident blocks sweep ONE window of a few MB per stream instead of 500 separate 256 KB runs - the HBM pages stay open
+    // (tools/lab/hbm_bw: 3R+1W streams reach 5.0-5.8 TB/s swept as windows; block-contiguous runs held this kernel at 4.0).
+    const long long sub0 = (long long)blockIdx.x * 4 + wave, sub_step = (long long)gridDim.x * 4;
 
     // register sets of the prefetch (PD2: two sub-tiles ahead instead of one)
     bf16x8 pxa[NVX], pga[NVG], pxb[NVX], pgb[NVG];
@@ -69,11 +72,13 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void pw_res_kernel(dig_pw_r
     };
     int cur_img = -1;
     if (sub0 < nsub) gload(sub0, pxa, pga);
-    constexpr bool PD2 = false;  // measured (B = 32, 256x256): a second set in flight changes nothing at N = 64 (219 vs 216 us) and costs 12 % at K = 192 - the
-                                 // kernel is not latency bound; the single-set loop is kept
-    if (PD2 && iters > 1 && sub0 + 4 < nsub) gload(sub0 + 4, pxb, pgb);
+    // Two sub-tiles ahead (PD2) was measured and is off: 219 vs 216 us at N = 64, +12 % at K = 192, +4 % on the fused-final-conv
+    // instantiation; removing the SiLU and the MFMAs altogether changes the N = 64 launches by 2 % (ablation builds): at
+    // 256x256 the kernel runs at the rate a plain 3-read + 1-write stream reaches (tools/lab/hbm_bw: 5.0-5.8 TB/s).
+    constexpr bool PD2 = false;
+    if (PD2 && iters > 1 && sub0 + sub_step < nsub) gload(sub0 + sub_step, pxb, pgb);
     auto step = [&](int it, bf16x8(&px)[NVX], bf16x8(&pg)[NVG]) {
-        const long long sub = sub0 + (long long)it * 4;
+        const long long sub = sub0 + (long long)it * sub_step;
         if (it >= iters || sub >= nsub) return;
         const int img = ((int)sub * 32) / a.rows_per_img;
         __builtin_amdgcn_wave_barrier();
@@ -96,9 +101,9 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void pw_res_kernel(dig_pw_r
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if constexpr (PD2) {
-            if (it + 2 < iters && sub + 8 < nsub) gload(sub + 8, px, pg);
+            if (it + 2 < iters && sub + 2 * sub_step < nsub) gload(sub + 2 * sub_step, px, pg);
         } else {
-            if (it + 1 < iters && sub + 4 < nsub) gload(sub + 4, px, pg);
+            if (it + 1 < iters && sub + sub_step < nsub) gload(sub + sub_step, px, pg);
         }
 
         const bf16* wsp = ws;
