@@ -275,6 +275,191 @@ __global__ __launch_bounds__(256, (KS * (int)sizeof(T) <= 8 ? LA_KV_WAVES : (KS 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// pass A, wave-private form (bf16, C = 64, large images of a whole number of 32-pixel tiles): one WAVE owns a run of
+// 32-pixel tiles and computes all four heads for them - nothing is shared between the waves but the read-only weights in
+// LDS, so there is no block barrier in the loop and every wave prefetches, stages (RMS-normalises) and multiplies on its own
+// schedule.  Both forms are bound by VALU issue (the exponentials, the bf16 packing, the staging), not by HBM: the
+// block-cooperative kernel above holds 1.8 TB/s on the 256x256 level.  What this form drops is the tail masking (the
+// dispatch only sends whole tiles here), the LDS-routed shuffles (DPP instead) and the barrier phases.  The NWV waves of a
+// block merge their online-softmax states in LDS at the end (fixed wave order), so a block is one `split` of the merge.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over each aligned group of 8 lanes, the same value (bitwise) in all 8: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror
+__device__ __forceinline__ float sum8_dpp(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    return v;
+}
+template <int KS, int NWV>
+__global__ __launch_bounds__(NWV * 64, 2) void la_kv_ctx_wave_kernel(dig_la_kvctx_args a) {
+    constexpr int C = KS * 16, CP = C + 8, LPR = C / 8, NV = 32 * LPR / 64;
+    static_assert(LPR == 8, "sum8_dpp reduces the 8 lanes of a 64-channel row");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16* wl = reinterpret_cast<bf16*>(smem);  // [256][CP]: k rows (head h: 32h..), then v rows (128 + 32h..), RMSNorm gain folded in
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    bf16* xs = wl + 256 * CP + wave * 32 * CP;  // this wave's 32 staged rows
+    const int b = blockIdx.y;
+    for (int i = tid; i < 256 * LPR; i += NWV * 64) {
+        const int row = i / LPR, v = i - row * LPR;
+        *reinterpret_cast<bf16x8*>(wl + row * CP + v * 8) = *reinterpret_cast<const bf16x8*>((const bf16*)a.wkv + (size_t)row * C + v * 8);
+    }
+    __syncthreads();
+    const bf16* x = (const bf16*)a.x + (size_t)b * a.n * C;
+    // the host checked n % 32 == 0 and n / 32 >= splits * NWV: every wave owns at least one whole tile
+    const int tiles = a.n / 32, wsplits = a.splits * NWV, tps = (tiles + wsplits - 1) / wsplits;
+    const int t_begin = min(tiles - 1, (blockIdx.x * NWV + wave) * tps), t_end = min(tiles, t_begin + tps);
+    f32x16 ctx[4];
+    float m_run[4], ksum[4];
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) ctx[h][e] = 0.f;
+        m_run[h] = -INFINITY;
+        ksum[h] = 0.f;
+    }
+    const float sqrtC = sqrtf((float)C);
+    Frag<bf16> pre[NV];
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int idx = lane + i * 64, row = idx / LPR, v = idx - row * LPR;
+            frag_load<bf16>(pre[i], x + (size_t)(t * 32 + row) * C + v * 8);
+        }
+    };
+    gload(t_begin);
+    for (int t = t_begin; t < t_end; t++) {
+        __builtin_amdgcn_wave_barrier();  // the previous tile's fragment reads are done (in-order LDS, same wave)
+#pragma unroll
+        for (int i = 0; i < NV; i++) {  // RMS-normalise while staging: F.normalize(x, dim=1) * sqrt(C) (ddp.py:108-114), g is in the weights
+            const int idx = lane + i * 64, row = idx / LPR, v = idx - row * LPR;
+            float xv[8], ssq = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                xv[j] = frag_get<bf16>(pre[i], j);
+                ssq += xv[j] * xv[j];
+            }
+            ssq = sum8_dpp(ssq);  // the 8 lanes of a row are adjacent
+            const float inv = sqrtC / fmaxf(sqrtf(ssq), 1e-12f);
+            Frag<bf16> f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) frag_set<bf16>(f, j, xv[j] * inv);
+            frag_store<bf16>(f, xs + row * CP + v * 8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (t + 1 < t_end) gload(t + 1);
+        Frag<bf16> fa[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) frag_load<bf16>(fa[ks], xs + r * CP + ks * 16 + hf * 8);
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            f32x16 ak, av;
+#pragma unroll
+            for (int e = 0; e < 16; e++) ak[e] = av[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                Frag<bf16> gk, gv;
+                frag_load<bf16>(gk, wl + (h * 32 + r) * CP + ks * 16 + hf * 8);
+                frag_load<bf16>(gv, wl + (128 + h * 32 + r) * CP + ks * 16 + hf * 8);
+                mma16<bf16>(ak, fa[ks], gk);
+                mma16<bf16>(av, fa[ks], gv);
+            }
+            float mt = ak[0];
+#pragma unroll
+            for (int e = 1; e < 16; e++) mt = fmaxf(mt, ak[e]);
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            const float m_new = fmaxf(m_run[h], mt);
+            const float f = exp2_fast((m_run[h] - m_new) * LOG2E);  // 0 on the first tile (m_run = -inf)
+#pragma unroll
+            for (int e = 0; e < 16; e++) ctx[h][e] *= f;
+            ksum[h] *= f;
+            m_run[h] = m_new;
+            const float mc = m_new * LOG2E;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                Frag<bf16> fA, fB;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float pe = exp2_fast(fmaf(ak[8 * s2 + j], LOG2E, -mc));
+                    ksum[h] += pe;
+                    frag_set<bf16>(fB, j, pe);
+                    frag_set<bf16>(fA, j, av[8 * s2 + j]);
+                }
+                mma16<bf16>(ctx[h], fA, fB);  // ctxT[e][d] += sum_p v[p][e] * kexp[p][d]
+            }
+        }
+    }
+    // ---- the block's waves merge (every wave has a finite running maximum): state -> LDS, M = max over the waves, every
+    // wave rescales its own part, head h's four parts are summed by wave h % NWV in wave order 0..NWV-1
+    __syncthreads();  // the weights and the staged rows are dead: the LDS is reused
+    float* ml = reinterpret_cast<float*>(smem);                  // [NWV][4][32] running maxima
+    float* sl = ml + NWV * 128;                                  // [NWV][4][32] scaled sums (written after M is known)
+    float* cl = sl + NWV * 128;                                  // [NWV][3 heads in flight][16][64] scaled contexts
+    static_assert(NWV == 4, "the merge deals head h to wave h");
+    static_assert((size_t)(2 * NWV * 128 + NWV * 3 * 1024) * 4 <= (size_t)(256 + NWV * 32) * CP * 2, "merge scratch fits the staging LDS");
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+        ksum[h] += __shfl_xor(ksum[h], 32, 64);
+        if (hf == 0) ml[(wave * 4 + h) * 32 + r] = m_run[h];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+        float M = ml[h * 32 + r];
+#pragma unroll
+        for (int w = 1; w < NWV; w++) M = fmaxf(M, ml[(w * 4 + h) * 32 + r]);
+        const float f = exp2_fast((m_run[h] - M) * LOG2E);
+        m_run[h] = M;
+        if (hf == 0) sl[(wave * 4 + h) * 32 + r] = ksum[h] * f;
+        if (h != wave) {
+            const int slot = h - (h > wave ? 1 : 0);
+#pragma unroll
+            for (int e = 0; e < 16; e++) cl[((wave * 3 + slot) * 16 + e) * 64 + lane] = ctx[h][e] * f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; e++) ctx[h][e] *= f;
+        }
+    }
+    __syncthreads();
+    const size_t slot = ((size_t)b * a.splits + blockIdx.x) * 4 + wave;  // head `wave`
+    f32x16 own;
+    float mo = 0.f;
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+        if (h == wave) {
+            own = ctx[h];
+            mo = m_run[h];
+        }
+    }
+    f32x16 sum;
+#pragma unroll
+    for (int e = 0; e < 16; e++) sum[e] = 0.f;
+    float ks = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; w++) {
+        ks += sl[(w * 4 + wave) * 32 + r];
+        if (w == wave) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) sum[e] += own[e];
+        } else {
+            const int sw = wave - (wave > w ? 1 : 0);
+#pragma unroll
+            for (int e = 0; e < 16; e++) sum[e] += cl[((w * 3 + sw) * 16 + e) * 64 + lane];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; e++) a.part[slot * 1024 + acc_row(e, lane) * 32 + r] = sum[e];
+    if (hf == 0) {
+        a.pmax[slot * 32 + r] = mo;
+        a.psum[slot * 32 + r] = ks;
+    }
+}
+
 // merge of the splits: ctx[b][h][d][e] = sum_s w_s part_s[e][d] / sum_s w_s ksum_s[d],  w_s = exp(m_s - max_s m_s)
 template <typename T> __global__ __launch_bounds__(256) void la_merge_kernel(dig_la_merge_args a) {
     const int bh = blockIdx.x, b = bh / 4, h = bh % 4;
@@ -296,31 +481,32 @@ template <typename T> __global__ __launch_bounds__(256) void la_merge_kernel(dig
 // merge + M_b in one launch (one 1024-thread block per (image, head)): the merged context stays in LDS (rounded through the
 // storage type, as the stand-alone merge stores it) and M_b[c][h*32+d] = sum_e Wout[c][h*32+e] ctx[d][e] (ddp.py:231 folded
 // into to_out) is formed right there - two launches (la_merge 19 us + a 128-problem batched GEMM 10 us) become one of a few us.
-#define LA_MAX_SPLITS 32
+#define LA_MAX_SPLITS 16
 template <typename T> __global__ __launch_bounds__(1024) void la_merge_mb_kernel(dig_la_merge_args a) {
     __shared__ float cs[32 * 33];
     const int bh = blockIdx.x, b = bh / 4, h = bh % 4;
     const int i = threadIdx.x, e = i >> 5, d = i & 31;
-    // all loads of the (at most LA_MAX_SPLITS) splits are issued before anything is used: the chain was one L2 round trip per split
-    float pm[LA_MAX_SPLITS], pt[LA_MAX_SPLITS], ps[LA_MAX_SPLITS];
-#pragma unroll
-    for (int s = 0; s < LA_MAX_SPLITS; s++) {
-        const size_t slot = ((size_t)b * a.splits + min(s, a.splits - 1)) * 4 + h;
-        pm[s] = a.pmax[slot * 32 + d];
-        pt[s] = a.part[slot * 1024 + i];
-        ps[s] = a.psum[slot * 32 + d];
-    }
+    // the loads of LA_MAX_SPLITS splits at a time are issued before anything is used (the chain was one L2 round trip per
+    // split); same order and arithmetic as la_merge_kernel: the two give identical contexts
     float M = -INFINITY;
-#pragma unroll
-    for (int s = 0; s < LA_MAX_SPLITS; s++)
-        if (s < a.splits) M = fmaxf(M, pm[s]);
+    for (int s = 0; s < a.splits; s++) M = fmaxf(M, a.pmax[(((size_t)b * a.splits + s) * 4 + h) * 32 + d]);
     float num = 0.f, den = 0.f;
+    for (int s0 = 0; s0 < a.splits; s0 += LA_MAX_SPLITS) {
+        float pm[LA_MAX_SPLITS], pt[LA_MAX_SPLITS], ps[LA_MAX_SPLITS];
 #pragma unroll
-    for (int s = 0; s < LA_MAX_SPLITS; s++) {  // same order and arithmetic as la_merge_kernel: the two give identical contexts
-        if (s < a.splits) {
-            const float w = __expf(pm[s] - M);
-            num += w * pt[s];
-            den += w * ps[s];
+        for (int s = 0; s < LA_MAX_SPLITS; s++) {
+            const size_t slot = ((size_t)b * a.splits + min(s0 + s, a.splits - 1)) * 4 + h;
+            pm[s] = a.pmax[slot * 32 + d];
+            pt[s] = a.part[slot * 1024 + i];
+            ps[s] = a.psum[slot * 32 + d];
+        }
+#pragma unroll
+        for (int s = 0; s < LA_MAX_SPLITS; s++) {
+            if (s0 + s < a.splits) {
+                const float w = __expf(pm[s] - M);
+                num += w * pt[s];
+                den += w * ps[s];
+            }
         }
     }
     const T v = from_f32<T>(num / den);
@@ -518,8 +704,31 @@ __global__ __launch_bounds__(NW * 64, (KS <= 8 ? 2 : 1)) void la_out_kernel(dig_
     }
 }
 
+#ifndef LA_WAVE_NWV
+#define LA_WAVE_NWV 4
+#endif
+// the wave-private kernel: bf16, C = 64, images of at least 8192 pixels in whole 32-pixel tiles (a function of the shape
+// only, never of the batch); a split is a block of LA_WAVE_NWV waves there
+template <typename T, int KS> constexpr bool la_wave_shape() { return sizeof(T) == 2 && KS == 4; }
 template <typename T, int KS> int launch_kvctx(const dig_la_kvctx_args* a, hipStream_t st) {
     constexpr int C = KS * 16;
+    if constexpr (la_wave_shape<T, KS>()) {
+        if (a->n >= 8192 && a->n % 32 == 0 && (long long)a->splits * LA_WAVE_NWV * 32 <= a->n) {
+            constexpr int NWV = LA_WAVE_NWV;
+            const size_t lds = (size_t)(256 + NWV * 32) * (C + 8) * sizeof(T);
+            static std::atomic<bool> attr_set[64];
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            dev &= 63;
+            if (!attr_set[dev].load(std::memory_order_acquire)) {
+                hipError_t e = hipFuncSetAttribute((const void*)la_kv_ctx_wave_kernel<KS, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                DIG_CHECK(e == hipSuccess, DIG_ELAUNCH, "la_kvctx: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
+                attr_set[dev].store(true, std::memory_order_release);
+            }
+            hipLaunchKernelGGL((la_kv_ctx_wave_kernel<KS, NWV>), dim3(a->splits, a->B), dim3(NWV * 64), lds, st, *a);
+            return 0;
+        }
+    }
     const size_t lds = (size_t)2 * 64 * (C + 8) * sizeof(T);  // double-buffered pixel tile
     constexpr bool WREG = sizeof(T) == 2 || KS <= 4;  // k/v weight fragments live in registers (fp32 fragments are twice as large)
     if (lds > 48 * 1024) {  // once per device and instantiation (not per call: the launchers must stay capture-safe after a warm-up)
@@ -586,7 +795,7 @@ extern "C" int dig_la_merge(const dig_la_merge_args* a, void* stream_) {
     hipStream_t st = (hipStream_t)stream_;
     DIG_CHECK(a && a->part && a->pmax && a->psum && (a->ctx || a->mb) && a->B > 0 && a->splits > 0, DIG_EINVAL, "la_merge: bad argument");
     if (a->mb) {
-        DIG_CHECK(a->wo && a->dim > 0 && a->splits <= LA_MAX_SPLITS, DIG_EINVAL, "la_merge: M_b output needs wo, dim and splits <= %d", LA_MAX_SPLITS);
+        DIG_CHECK(a->wo && a->dim > 0, DIG_EINVAL, "la_merge: M_b output needs wo and dim");
         DIG_CHECK(((uintptr_t)a->wo | (uintptr_t)a->mb) % 16 == 0, DIG_EALIGN, "la_merge: wo / mb must be 16-byte aligned");
         if (a->dtype == DIG_BF16) hipLaunchKernelGGL(la_merge_mb_kernel<bf16>, dim3(a->B * 4), dim3(1024), 0, st, *a);
         else hipLaunchKernelGGL(la_merge_mb_kernel<float>, dim3(a->B * 4), dim3(1024), 0, st, *a);

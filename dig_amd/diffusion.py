@@ -340,8 +340,12 @@ def _linear_attention_unfused(p, x):
     return ops.rmsnorm(y, p["g2"], res=x)
 
 
-def la_splits(n):
-    """Pixel splits of the fused LinearAttention's pass A for an image of n pixels (independent of the batch size)."""
+def la_splits(n, C=0, dtype=None):
+    """Pixel splits of the fused LinearAttention's pass A for an image of n pixels (independent of the batch size).
+    bf16, C = 64 at >= 8192 pixels in whole 32-pixel tiles runs the wave-private kernel, whose splits are blocks of four
+    waves (each wave a run of tiles, merged in the block): 16 of them per image."""
+    if C == 64 and dtype == torch.bfloat16 and n >= 8192 and n % 32 == 0:
+        return 16
     return max(1, min(32, ((n + 63) // 64) // 4))
 
 
@@ -358,7 +362,7 @@ def _linear_attention(p, x):
     tiles = (n + 63) // 64
     # pixel splits of pass A: a function of n ONLY, so that an image goes through the same fp32 merge order whatever batch
     # it sits in (a rank's shard of a batch is then bitwise equal to the same images inside the full batch)
-    splits = la_splits(n)
+    splits = la_splits(n, C, dt)
     part = torch.empty(B, splits, 4, 32, 32, dtype=torch.float32, device=x.device)
     pmax = torch.empty(B, splits, 4, 32, dtype=torch.float32, device=x.device)
     psum = torch.empty(B, splits, 4, 32, dtype=torch.float32, device=x.device)
