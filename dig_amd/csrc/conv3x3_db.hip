@@ -163,7 +163,8 @@ template <int NW, bool PRO, int BN, int WP = BN> __global__ __launch_bounds__(64
         }
     };
     // ---- PRO: GroupNorm-apply + SiLU (ddp.py:160-166) of chunk ci, in place on the slots this lane's DMA wrote (out-of-image
-    // slots stay zero: the convolution pads the ACTIVATED tensor).  afl: this image's [C0][2] (a, b) table in LDS.
+    // slots stay zero: the convolution pads the ACTIVATED tensor).  afl: this image's [C0][2] table in LDS, (a, b) pre-scaled
+    // by -log2(e) (silu_pre, common.hpp).
     float* const afl = reinterpret_cast<float*>(smem + Cfg::AFF_OFF);
     auto hpro = [&](int ci, unsigned char* buf, int i) {
         if ((wave + i * NW) < Cfg::HPIECES && dval[i]) {
@@ -173,8 +174,8 @@ template <int NW, bool PRO, int BN, int WP = BN> __global__ __launch_bounds__(64
 #pragma unroll
             for (int j4 = 0; j4 < 4; j4++) {
                 const f32x4 ab = *reinterpret_cast<const f32x4*>(af + j4 * 4);
-                v[2 * j4] = (bf16)silu_f(ab[0] * (float)v[2 * j4] + ab[1]);
-                v[2 * j4 + 1] = (bf16)silu_f(ab[2] * (float)v[2 * j4 + 1] + ab[3]);
+                v[2 * j4] = (bf16)silu_pre(ab[0], ab[1], (float)v[2 * j4]);
+                v[2 * j4 + 1] = (bf16)silu_pre(ab[2], ab[3], (float)v[2 * j4 + 1]);
             }
             *sp = v;
         }
@@ -207,7 +208,7 @@ template <int NW, bool PRO, int BN, int WP = BN> __global__ __launch_bounds__(64
     hdma(0, smem);
     if constexpr (PRO) {
         const float* asrc = p.aff0 + (size_t)b * p.C[0] * 2;
-        for (int i = tid; i < p.C[0] / 2; i += NTHREADS) *reinterpret_cast<f32x4*>(afl + i * 4) = *reinterpret_cast<const f32x4*>(asrc + i * 4);
+        for (int i = tid; i < p.C[0] / 2; i += NTHREADS) *reinterpret_cast<f32x4*>(afl + i * 4) = *reinterpret_cast<const f32x4*>(asrc + i * 4) * SILU_PRE;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
         __syncthreads();                                   // the affine table is complete
 #pragma unroll

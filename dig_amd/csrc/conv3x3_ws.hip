@@ -177,7 +177,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
     };
-    // GroupNorm-apply + SiLU prologue: v = a x + b, silu = v / (1 + 2^(-v log2 e)).  Plain scalar
+    // GroupNorm-apply + SiLU prologue: silu_pre (common.hpp) on the affine pre-scaled by -log2(e) in aff_l.  Plain scalar
     // f32 VALU on purpose: gfx950's SIMD-32 gains nothing from v_pk_*_f32 and pays extra issue cycles for them beside
     // MFMAs (MI355X_MICROARCH.md, cycle constants) - the file is built with -fno-slp-vectorize so the compiler keeps it so.
     struct Aff {
@@ -201,10 +201,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const float x0 = __builtin_bit_cast(float, w[j] << 16), x1 = __builtin_bit_cast(float, w[j] & (int)0xffff0000);
-                    const float v0 = fmaf(A.pa[2 * j], x0, A.pb[2 * j]), v1 = fmaf(A.pa[2 * j + 1], x1, A.pb[2 * j + 1]);
-                    const float d0 = __builtin_amdgcn_exp2f(v0 * -1.4426950408889634f) + 1.0f;
-                    const float d1 = __builtin_amdgcn_exp2f(v1 * -1.4426950408889634f) + 1.0f;
-                    const float o0 = v0 * __builtin_amdgcn_rcpf(d0), o1 = v1 * __builtin_amdgcn_rcpf(d1);
+                    const float o0 = silu_pre(A.pa[2 * j], A.pb[2 * j], x0), o1 = silu_pre(A.pa[2 * j + 1], A.pb[2 * j + 1], x1);
                     w[j] = __builtin_bit_cast(int, bf16x2{(bf16)o0, (bf16)o1});
                 }
             }
@@ -391,7 +388,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned long long ws_t_entry = __builtin_amdgcn_s_memtime();
     const unsigned long long ws_rt_entry = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (p.aff && tile_of(0) < p.ntiles && tg < 128) aff_l[tg] = p.aff[(size_t)(tile_of(0) / tiles_img) * 128 + tg];
+    if (p.aff && tile_of(0) < p.ntiles && tg < 128) aff_l[tg] = p.aff[(size_t)(tile_of(0) / tiles_img) * 128 + tg] * SILU_PRE;
     __syncthreads();  // weights, bias and the first affine are in LDS
     for (int ph = -1; ph <= 2 * K; ph++) {
         const int q = ph - grp;
@@ -505,7 +502,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int k = q >> 1;
             const bool nxt = p.aff && k >= 0 && k + 1 < K && tile_of(k + 1) < p.ntiles && tg < 128;
             float av = 0.f;
-            if (nxt) av = p.aff[(size_t)(tile_of(k + 1) / tiles_img) * 128 + tg];
+            if (nxt) av = p.aff[(size_t)(tile_of(k + 1) / tiles_img) * 128 + tg] * SILU_PRE;
 #ifndef WS_NO_COMPUTE
             compute();
 #endif

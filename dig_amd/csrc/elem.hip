@@ -12,6 +12,16 @@ __global__ void gn_finalize_kernel(dig_gn_finalize_args a) {
     const int b = blockIdx.x / a.groups, g = blockIdx.x % a.groups;
     const int cpg = a.C / a.groups;
     const float* st = a.stats + ((size_t)b * a.groups + g) * a.tiles * 2;
+    // the first channel's parameters are fetched beside the partials, not after the reduction (the kernel is one chain of
+    // dependent L2 round trips: partials -> sums -> parameters -> store)
+    const int c0 = g * cpg + min((int)threadIdx.x, cpg - 1);
+    const float ga0 = a.gamma[c0], be0 = a.beta[c0];
+    float sc0 = 1.0f, sh0 = 0.0f;
+    if (a.ss) {
+        const float* row = a.ss + (size_t)b * a.ss_ld + a.ss_off;
+        sc0 = row[c0] + 1.0f;
+        sh0 = row[a.C + c0];
+    }
     double s = 0.0, ss = 0.0;
     // 8 partials per round trip (all loads issued before the first add; the adds keep their order, so the sums are the same
     // bits as the plain loop's): at 256x256 the weight-stationary kernel leaves 1024 partials per (image, group)
@@ -43,11 +53,12 @@ __global__ void gn_finalize_kernel(dig_gn_finalize_args a) {
     const float meanf = (float)mean;
     for (int i = threadIdx.x; i < cpg; i += 64) {
         const int c = g * cpg + i;
-        float ga = a.gamma[c] * rstd;
-        float be = a.beta[c] - meanf * ga;
+        const bool first = i == (int)threadIdx.x;
+        float ga = (first ? ga0 : a.gamma[c]) * rstd;
+        float be = (first ? be0 : a.beta[c]) - meanf * ga;
         if (a.ss) {
             const float* row = a.ss + (size_t)b * a.ss_ld + a.ss_off;
-            const float sc = row[c] + 1.0f, sh = row[a.C + c];
+            const float sc = first ? sc0 : row[c] + 1.0f, sh = first ? sh0 : row[a.C + c];
             ga *= sc;
             be = be * sc + sh;
         }
