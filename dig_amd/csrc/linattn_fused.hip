@@ -486,13 +486,11 @@ template <typename T> __global__ __launch_bounds__(1024) void la_merge_mb_kernel
     __shared__ float cs[32 * 33];
     const int bh = blockIdx.x, b = bh / 4, h = bh % 4;
     const int i = threadIdx.x, e = i >> 5, d = i & 31;
-    // the loads of LA_MAX_SPLITS splits at a time are issued before anything is used (the chain was one L2 round trip per
-    // split); same order and arithmetic as la_merge_kernel: the two give identical contexts
-    float M = -INFINITY;
-    for (int s = 0; s < a.splits; s++) M = fmaxf(M, a.pmax[(((size_t)b * a.splits + s) * 4 + h) * 32 + d]);
-    float num = 0.f, den = 0.f;
-    for (int s0 = 0; s0 < a.splits; s0 += LA_MAX_SPLITS) {
-        float pm[LA_MAX_SPLITS], pt[LA_MAX_SPLITS], ps[LA_MAX_SPLITS];
+    // the loads of LA_MAX_SPLITS splits at a time are issued before anything is used (a loop over the splits is one L2 round
+    // trip per split - for the maxima as well as for the sums); same order and arithmetic as la_merge_kernel: the two give
+    // identical contexts
+    float pm[LA_MAX_SPLITS], pt[LA_MAX_SPLITS], ps[LA_MAX_SPLITS];
+    auto load_chunk = [&](int s0) {
 #pragma unroll
         for (int s = 0; s < LA_MAX_SPLITS; s++) {
             const size_t slot = ((size_t)b * a.splits + min(s0 + s, a.splits - 1)) * 4 + h;
@@ -500,6 +498,21 @@ template <typename T> __global__ __launch_bounds__(1024) void la_merge_mb_kernel
             pt[s] = a.part[slot * 1024 + i];
             ps[s] = a.psum[slot * 32 + d];
         }
+    };
+    load_chunk(0);
+    float M = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < LA_MAX_SPLITS; s++) M = fmaxf(M, pm[s]);  // (slots past the end repeat the last split)
+    for (int s0 = LA_MAX_SPLITS; s0 < a.splits; s0 += LA_MAX_SPLITS) {
+        float q[LA_MAX_SPLITS];
+#pragma unroll
+        for (int s = 0; s < LA_MAX_SPLITS; s++) q[s] = a.pmax[(((size_t)b * a.splits + min(s0 + s, a.splits - 1)) * 4 + h) * 32 + d];
+#pragma unroll
+        for (int s = 0; s < LA_MAX_SPLITS; s++) M = fmaxf(M, q[s]);
+    }
+    float num = 0.f, den = 0.f;
+    for (int s0 = 0; s0 < a.splits; s0 += LA_MAX_SPLITS) {
+        if (s0) load_chunk(s0);
 #pragma unroll
         for (int s = 0; s < LA_MAX_SPLITS; s++) {
             if (s0 + s < a.splits) {
