@@ -1,0 +1,403 @@
+// Backward pass and optimiser step of the MCTformer classification losses (models/model_ECCV24_DiG.py:337-341,406-410,
+// 424-425: loss_trm.backward(); opt_trm.step()), gfx950, fp32 throughout (the CAM path's arithmetic type).
+//
+// The reference has no backward code of its own - autograd derives it from the forward modules (vision_transformer.py:54-103,
+// 177-196; mctformer.py:227-300).  What is here are the adjoints of those forward operators, composed by dig_amd/train.py:
+//   gemm_f32        C = alpha * A B (+ bias) (+ C) with ARBITRARY element strides on A and B and two-level batching: every
+//                   product of the backward pass (dY W, dY^T X, P^T dO, dO V^T, dS K, dS^T Q) is one launch of it on the
+//                   tensors where they lie - nothing is transposed in memory.  fp32 MFMA (v_mfma_f32_32x32x2_f32), 128x64
+//                   tile, k-major LDS tiles, the next tile's global loads in flight under the MFMAs.
+//   layernorm_bwd   dx (+ the residual path's gradient) and per-row-block partial sums of dgamma / dbeta
+//   colsum          deterministic two-stage column sums (bias gradients, the LayerNorm partials, pos_embed over the batch)
+//   gelu_bwd, softmax_bwd, msm_grad, head_pool_bwd   adjoints of the erf-GELU, the row softmax (scaled logits), the
+//                   multilabel soft-margin loss and the top-3 pooled patch logits
+//   adamw           torch.optim.AdamW's update (decoupled decay, bias-corrected moments), one launch per parameter
+// No atomics: every sum has a fixed order, so a step is bitwise reproducible.
+#include "common.hpp"
+
+namespace {
+
+#define STREAM hipStream_t stream = (hipStream_t)stream_
+
+// ------------------------------------------------------------------------------------------------------------------------
+// strided fp32 GEMM.  Block = 256 threads = 4 waves, tile 128 (M) x 64 (N), BK = 16; wave w owns rows 32w..32w+31 and both
+// 32-column halves (2 accumulator tiles).  LDS tiles are k-major (As[k][m], Bs[k][n]) so that an MFMA operand read - lane l
+// wants element (row or column l & 31, k = l >> 5) - is 32 consecutive floats per half wave.
+constexpr int GBM = 128, GBN = 64, GBK = 16, GPA = GBM + 4, GPB = GBN + 4;
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(dig_gemm_f32_args a) {
+    __shared__ float As[2][GBK][GPA];
+    __shared__ float Bs[2][GBK][GPB];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int z = blockIdx.z, zo = z / a.z_inner, zi = z - zo * a.z_inner;
+    const float* A = a.a + (size_t)zo * a.sa_o + (size_t)zi * a.sa_i;
+    const float* B = a.b + (size_t)zo * a.sb_o + (size_t)zi * a.sb_i;
+    float* C = a.c + (size_t)zo * a.sc_o + (size_t)zi * a.sc_i;
+    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    // global -> register staging: 8 A elements and 4 B elements per thread and K tile.  The thread -> element map follows
+    // the contiguous direction of each operand (uniform branch), so a wave's loads are whole 256-byte runs either way.
+    const bool a_kfast = a.sak == 1, b_kfast = a.sbk == 1 && a.sbn != 1;
+    float ra[8], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            int mm, kk;
+            if (a_kfast) { kk = tid & 15; mm = (tid >> 4) + 16 * i; }
+            else { mm = (tid & 127); kk = (tid >> 7) + 2 * i; }
+            const int m = m0 + mm, k = k0 + kk;
+            ra[i] = (m < a.M && k < a.K) ? A[(size_t)m * a.sam + (size_t)k * a.sak] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int nn, kk;
+            if (b_kfast) { kk = tid & 15; nn = (tid >> 4) + 16 * i; }
+            else { nn = tid & 63; kk = (tid >> 6) + 4 * i; }
+            const int n = n0 + nn, k = k0 + kk;
+            rb[i] = (n < a.N && k < a.K) ? B[(size_t)k * a.sbk + (size_t)n * a.sbn] : 0.f;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            int mm, kk;
+            if (a_kfast) { kk = tid & 15; mm = (tid >> 4) + 16 * i; }
+            else { mm = (tid & 127); kk = (tid >> 7) + 2 * i; }
+            As[buf][kk][mm] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int nn, kk;
+            if (b_kfast) { kk = tid & 15; nn = (tid >> 4) + 16 * i; }
+            else { nn = tid & 63; kk = (tid >> 6) + 4 * i; }
+            Bs[buf][kk][nn] = rb[i];
+        }
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[j][e] = 0.f;
+    const int nk = (a.K + GBK - 1) / GBK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * GBK);
+#pragma unroll
+        for (int k2 = 0; k2 < GBK / 2; k2++) {
+            const float av = As[buf][2 * k2 + hf][32 * wave + r];
+            const float b0 = Bs[buf][2 * k2 + hf][r], b1 = Bs[buf][2 * k2 + hf][32 + r];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[1], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);  // the other buffer: its last readers passed the barrier of the previous iteration
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int n = n0 + 32 * j + r;
+        if (n >= a.N) continue;
+        const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int m = m0 + 32 * wave + acc_row(e, lane);
+            if (m < a.M) {
+                float* p = C + (size_t)m * a.ldc + n;
+                float v = a.alpha * acc[j][e] + bv;
+                if (a.accumulate) v += *p;
+                *p = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// LayerNorm backward: one wave per row, 32 rows per 256-thread block.  y = (x - mu) rstd g + b:
+//   dx = rstd (g dy - mean(g dy) - xhat mean(g dy xhat)) [+ add],  dgamma = sum_rows dy xhat,  dbeta = sum_rows dy
+constexpr int LN_ROWS = 32, LN_MAXV = 16;  // D <= 64 * LN_MAXV
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(dig_layernorm_bwd_args a) {
+    __shared__ float red[4][2][256];  // one 256-column slice of the four waves' partial sums at a time
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = (a.D + 63) / 64;
+    float dg[LN_MAXV], db[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++) dg[i] = db[i] = 0.f;
+    const long long row0 = (long long)blockIdx.x * LN_ROWS;
+    for (int rr = wave; rr < LN_ROWS; rr += 4) {  // fixed row order per wave
+        const long long row = row0 + rr;
+        if (row >= a.rows) break;
+        const float* x = a.x + (size_t)row * a.D;
+        const float* dy = a.dy + (size_t)row * a.D;
+        float xv[LN_MAXV], gv[LN_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; i++) {
+            const int c = lane + 64 * i;
+            xv[i] = (i < nv && c < a.D) ? x[c] : 0.f;
+            s += xv[i];
+        }
+        const float mu = wave_sum(s) / (float)a.D;
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; i++) {
+            const int c = lane + 64 * i;
+            const float d = (i < nv && c < a.D) ? xv[i] - mu : 0.f;
+            v += d * d;
+        }
+        const float rstd = rsqrtf(wave_sum(v) / (float)a.D + a.eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; i++) {
+            const int c = lane + 64 * i;
+            const bool ok = i < nv && c < a.D;
+            const float xh = ok ? (xv[i] - mu) * rstd : 0.f;
+            const float d = ok ? dy[c] : 0.f;
+            const float g = ok ? a.gamma[c] * d : 0.f;
+            dg[i] += d * xh;
+            db[i] += d;
+            s1 += g;
+            s2 += g * xh;
+            xv[i] = xh;
+            gv[i] = g;
+        }
+        s1 = wave_sum(s1) / (float)a.D;
+        s2 = wave_sum(s2) / (float)a.D;
+        float* dx = a.dx + (size_t)row * a.D;
+        const float* add = a.add ? a.add + (size_t)row * a.D : nullptr;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; i++) {
+            const int c = lane + 64 * i;
+            if (i < nv && c < a.D) {
+                float o = rstd * (gv[i] - s1 - xv[i] * s2);
+                if (add) o += add[c];
+                dx[c] = o;
+            }
+        }
+    }
+    // the four waves' partial sums, added in wave order; red is re-used per 256-column slice
+    float* part = a.part + (size_t)blockIdx.x * 2 * a.D;
+#pragma unroll
+    for (int q = 0; q < LN_MAXV / 4; q++) {
+        if (q * 4 >= nv) break;  // uniform
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            red[wave][0][lane + 64 * i] = dg[4 * q + i];
+            red[wave][1][lane + 64 * i] = db[4 * q + i];
+        }
+        __syncthreads();
+        const int c = q * 256 + threadIdx.x;
+        if (c < a.D) {
+            part[c] = ((red[0][0][threadIdx.x] + red[1][0][threadIdx.x]) + red[2][0][threadIdx.x]) + red[3][0][threadIdx.x];
+            part[a.D + c] = ((red[0][1][threadIdx.x] + red[1][1][threadIdx.x]) + red[2][1][threadIdx.x]) + red[3][1][threadIdx.x];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// column sums: stage 1 sums chunks of CS_ROWS rows (4 row lanes x 64 columns per block, fixed order), stage 2 the chunks
+constexpr int CS_ROWS = 128;
+__global__ __launch_bounds__(256) void colsum1_kernel(const float* x, float* ws, long long M, int N, long long ld) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const long long r0 = (long long)blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+    float s = 0.f;
+    if (col < N)
+        for (long long rw = r0 + rl; rw < r1; rw += 4) s += x[(size_t)rw * ld + col];
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && col < N) ws[(size_t)blockIdx.y * N + col] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void colsum2_kernel(const float* ws, float* out, int chunks, int N, float scale, int accumulate) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= N) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; c++) s += ws[(size_t)c * N + col];
+    s *= scale;
+    out[col] = accumulate ? out[col] + s : s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* x, const float* dy, float* dx, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = x[i];
+        const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752f));
+        const float pdf = 0.3989422804014327f * expf(-0.5f * v * v);
+        dx[i] = dy[i] * (cdf + v * pdf);
+    }
+}
+
+// softmax backward on rows of n: ds = scale * p * (dp - sum_j p_j dp_j), in place over dp; one wave per row
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* p, float* dp, long long rows, int n, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* pr = p + (size_t)row * n;
+    float* dr = dp + (size_t)row * n;
+    float s = 0.f;
+    for (int j = lane; j < n; j += 64) s += pr[j] * dr[j];
+    s = wave_sum(s);
+    for (int j = lane; j < n; j += 64) dr[j] = scale * pr[j] * (dr[j] - s);
+}
+
+// d/dx of scale * F.multilabel_soft_margin_loss(x, y): scale * (sigmoid(x) - y) / (B C)
+__global__ __launch_bounds__(256) void msm_grad_kernel(dig_msm_grad_args a) {
+    const int n = a.B * a.C;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = a.x[i];
+    const float sg = x >= 0.f ? 1.0f / (1.0f + expf(-x)) : expf(x) / (1.0f + expf(x));
+    a.dx[i] = a.scale * (sg - a.y[i]) / (float)n;
+}
+
+// adjoint of head_pool: dpooled[b][c] / k goes to the k largest positive and the k largest negative-magnitude positions of
+// channel c (mctformer.py:300: topk(relu(x)) - topk(relu(-x)); ReLU passes no gradient at 0).  out [B][P][Cp] is written
+// in full: zero elsewhere and in the padding channels C..Cp-1.  One wave per (b, c), c < Cp.
+struct Top3i {
+    float v[3];
+    int i[3];
+    __device__ __forceinline__ void init() {
+        v[0] = v[1] = v[2] = -INFINITY;
+        i[0] = i[1] = i[2] = -1;
+    }
+    __device__ __forceinline__ void push(float x, int ix) {
+        if (x > v[0]) { v[2] = v[1]; i[2] = i[1]; v[1] = v[0]; i[1] = i[0]; v[0] = x; i[0] = ix; }
+        else if (x > v[1]) { v[2] = v[1]; i[2] = i[1]; v[1] = x; i[1] = ix; }
+        else if (x > v[2]) { v[2] = x; i[2] = ix; }
+    }
+    __device__ __forceinline__ void pop() { v[0] = v[1]; i[0] = i[1]; v[1] = v[2]; i[1] = i[2]; v[2] = -INFINITY; i[2] = -1; }
+};
+__global__ __launch_bounds__(256) void head_pool_bwd_kernel(dig_head_pool_bwd_args a) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long long)a.B * a.Cp) return;
+    const int b = (int)(row / a.Cp), c = (int)(row % a.Cp);
+    float* out = a.dhead + (size_t)b * a.P * a.Cp + c;
+    for (int p = lane; p < a.P; p += 64) out[(size_t)p * a.Cp] = 0.f;
+    if (c >= a.C) return;
+    const float* in = a.head + (size_t)b * a.P * a.C + c;
+    Top3i pos, neg;
+    pos.init();
+    neg.init();
+    for (int p = lane; p < a.P; p += 64) {
+        const float v = in[(size_t)p * a.C];
+        pos.push(fmaxf(v, 0.f), p);
+        neg.push(fmaxf(-v, 0.f), p);
+    }
+    const int k = min(3, a.P);
+    const float g = a.dpooled[(size_t)b * a.C + c] / (float)k;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the zero fill above precedes the scattered stores below
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        Top3i& t = side ? neg : pos;
+        for (int i = 0; i < k; i++) {
+            const float m = wave_max(t.v[0]);
+            const unsigned long long owners = __ballot(t.v[0] == m);
+            if (lane == (int)__builtin_ctzll(owners)) {
+                if (m > 0.f) out[(size_t)t.i[0] * a.Cp] = g;  // a position is positive or negative, never both: no overlap between the sides
+                t.pop();
+            }
+        }
+    }
+}
+
+// torch.optim.AdamW, one parameter tensor: p *= 1 - lr wd; m, v updated; p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adamw_kernel(dig_adamw_args a) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
+        const float g = a.g[i];
+        float p = a.p[i] * (1.0f - a.lr * a.wd);
+        const float m = a.beta1 * a.m[i] + (1.0f - a.beta1) * g;
+        const float v = a.beta2 * a.v[i] + (1.0f - a.beta2) * g * g;
+        a.m[i] = m;
+        a.v[i] = v;
+        const float denom = sqrtf(v) / a.sqrt_bc2 + a.eps;
+        a.p[i] = p - a.step_size * (m / denom);
+    }
+}
+
+}  // namespace
+
+extern "C" int dig_gemm_f32(const dig_gemm_f32_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->a && a->b && a->c, DIG_EINVAL, "gemm_f32: null pointer");
+    DIG_CHECK(a->M > 0 && a->N > 0 && a->K > 0 && a->batch > 0 && a->z_inner > 0 && a->batch % a->z_inner == 0 && a->ldc >= a->N, DIG_EINVAL,
+              "gemm_f32: bad shape M=%d N=%d K=%d batch=%d z_inner=%d ldc=%d", a->M, a->N, a->K, a->batch, a->z_inner, a->ldc);
+    DIG_CHECK(a->batch <= 65535, DIG_EINVAL, "gemm_f32: batch %d > 65535", a->batch);
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(a->N, GBN), cdiv(a->M, GBM), a->batch), dim3(256), 0, stream, *a);
+    DIG_LAUNCH_CHECK("gemm_f32");
+    return DIG_OK;
+}
+
+extern "C" int dig_layernorm_bwd_blocks(long long rows) { return (int)((rows + LN_ROWS - 1) / LN_ROWS); }
+
+extern "C" int dig_layernorm_bwd(const dig_layernorm_bwd_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->x && a->gamma && a->dy && a->dx && a->part, DIG_EINVAL, "layernorm_bwd: null pointer");
+    DIG_CHECK(a->rows > 0 && a->D > 0 && a->D <= 64 * LN_MAXV, DIG_EINVAL, "layernorm_bwd: bad shape rows=%lld D=%d (D <= %d)", a->rows, a->D, 64 * LN_MAXV);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)dig_layernorm_bwd_blocks(a->rows)), dim3(256), 0, stream, *a);
+    DIG_LAUNCH_CHECK("layernorm_bwd");
+    return DIG_OK;
+}
+
+extern "C" int dig_colsum_chunks(long long M) { return (int)((M + CS_ROWS - 1) / CS_ROWS); }
+
+extern "C" int dig_colsum(const dig_colsum_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->x && a->ws && a->out, DIG_EINVAL, "colsum: null pointer");
+    DIG_CHECK(a->M > 0 && a->N > 0 && a->ld >= a->N, DIG_EINVAL, "colsum: bad shape M=%lld N=%d ld=%lld", a->M, a->N, a->ld);
+    const int chunks = dig_colsum_chunks(a->M);
+    DIG_CHECK(chunks <= 65535, DIG_EINVAL, "colsum: %d row chunks > 65535", chunks);
+    hipLaunchKernelGGL(colsum1_kernel, dim3(cdiv(a->N, 64), chunks), dim3(256), 0, stream, a->x, a->ws, a->M, a->N, a->ld);
+    hipLaunchKernelGGL(colsum2_kernel, dim3(cdiv(a->N, 256)), dim3(256), 0, stream, (const float*)a->ws, a->out, chunks, a->N, a->scale, a->accumulate);
+    DIG_LAUNCH_CHECK("colsum");
+    return DIG_OK;
+}
+
+extern "C" int dig_gelu_bwd(const dig_gelu_bwd_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->x && a->dy && a->dx && a->n > 0, DIG_EINVAL, "gelu_bwd: bad argument");
+    const long long blocks = (a->n + 255) / 256;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream, a->x, a->dy, a->dx, a->n);
+    DIG_LAUNCH_CHECK("gelu_bwd");
+    return DIG_OK;
+}
+
+extern "C" int dig_softmax_bwd(const dig_softmax_bwd_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->p && a->dp && a->rows > 0 && a->n > 0, DIG_EINVAL, "softmax_bwd: bad argument");
+    const long long blocks = (a->rows + 3) / 4;
+    DIG_CHECK(blocks < (1ll << 31), DIG_EINVAL, "softmax_bwd: too many rows");
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a->p, a->dp, a->rows, a->n, a->scale);
+    DIG_LAUNCH_CHECK("softmax_bwd");
+    return DIG_OK;
+}
+
+extern "C" int dig_msm_grad(const dig_msm_grad_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->x && a->y && a->dx && a->B > 0 && a->C > 0, DIG_EINVAL, "msm_grad: bad argument");
+    hipLaunchKernelGGL(msm_grad_kernel, dim3(cdiv(a->B * a->C, 256)), dim3(256), 0, stream, *a);
+    DIG_LAUNCH_CHECK("msm_grad");
+    return DIG_OK;
+}
+
+extern "C" int dig_head_pool_bwd(const dig_head_pool_bwd_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->head && a->dpooled && a->dhead, DIG_EINVAL, "head_pool_bwd: null pointer");
+    DIG_CHECK(a->B > 0 && a->P > 0 && a->C > 0 && a->Cp >= a->C, DIG_EINVAL, "head_pool_bwd: bad shape B=%d P=%d C=%d Cp=%d", a->B, a->P, a->C, a->Cp);
+    hipLaunchKernelGGL(head_pool_bwd_kernel, dim3((unsigned)(((long long)a->B * a->Cp + 3) / 4)), dim3(256), 0, stream, *a);
+    DIG_LAUNCH_CHECK("head_pool_bwd");
+    return DIG_OK;
+}
+
+extern "C" int dig_adamw(const dig_adamw_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->p && a->g && a->m && a->v && a->n > 0, DIG_EINVAL, "adamw: bad argument");
+    DIG_CHECK(a->sqrt_bc2 > 0.f && a->eps >= 0.f, DIG_EINVAL, "adamw: bad bias correction / eps");
+    const long long blocks = (a->n + 255) / 256;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, *a);
+    DIG_LAUNCH_CHECK("adamw");
+    return DIG_OK;
+}

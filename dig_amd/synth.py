@@ -105,3 +105,11 @@ def synth_labels(B, C, seed=99):
         for j in range(k):
             lab[i, int(u[1 + j] * C) % C] = 1.0
     return lab
+
+
+def sample_index(name, numel, n=256):
+    """The fixed sample of a parameter-sized tensor that the backward fixture keeps (a full ViT-S gradient set is 88 MB):
+    n flat indices from a generator seeded by the parameter's name."""
+    import zlib
+    gen = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+    return torch.randint(0, numel, (min(n, numel),), generator=gen)

@@ -1,0 +1,289 @@
+"""Training step of the MCTformer classification losses on the HIP kernels.
+
+model_WSSS.update (models/model_ECCV24_DiG.py:318-341,396-410,424-425):
+
+    self.opt_trm.zero_grad(); outputs = self.net_trm(self.img, ...)
+    loss_cls = W[0] * (multilabel_soft_margin(cls) + multilabel_soft_margin(pcls))        (+ the same on img_diff: loss_cls_diff)
+    loss_trm.backward(); self.opt_trm.step()
+
+The reference leaves the backward to autograd over vision_transformer.py:54-103,177-196 and mctformer.py:227-300.  Here the
+forward is re-run with its intermediates kept (`forward_train`), and `backward_cls` walks the same operators in reverse on the
+adjoint kernels of csrc/train.hip (dig_gemm_f32 with transposed operands as stride pairs, dig_layernorm_bwd, dig_gelu_bwd,
+dig_softmax_bwd, dig_head_pool_bwd, dig_msm_grad, dig_colsum); `AdamW` is torch.optim.AdamW's update with timm's no-decay
+filter.  fp32, eval-mode semantics (no DropPath / dropout: the product's MCTformer refuses drop rates), no atomics - a step is
+bitwise reproducible.  Built for the loss terms that need one plain MCTformer pass (loss_cls, loss_cls_diff); the LFCA / KD,
+CAM-consistency and rcams-consistency terms have forward kernels only (dig_amd/losses.py).
+torch allocates, copies and reshapes; every arithmetic operation is a C-ABI launch.  There is no CPU fallback.
+"""
+import math
+
+import torch
+
+from . import ops
+from ._lib import call, lib
+from .cam import _layernorm, _pack, _pos_embed
+
+F32 = torch.float32
+
+
+def _p(x):
+    if x is None:
+        return None
+    if isinstance(x, tuple):
+        t, off = x
+        return t.data_ptr() + off * 4
+    return x.data_ptr()
+
+
+def gemm_f32(a, b, c, M, N, K, *, sam, sak, sbk, sbn, ldc=None, bias=None, alpha=1.0, batch=1, z_inner=1,
+             sa=(0, 0), sb=(0, 0), sc=(0, 0), accumulate=False):
+    """dig_gemm_f32: C[z][m][n] = alpha * sum_k A[z][m*sam + k*sak] * B[z][k*sbk + n*sbn] (+ bias) (+ C).  a / b / c are fp32
+    tensors or (tensor, element offset); strides in elements."""
+    t = c[0] if isinstance(c, tuple) else c
+    with torch.cuda.device(t.device):
+        call("gemm_f32", a=_p(a), b=_p(b), c=_p(c), bias=bias, sam=sam, sak=sak, sbk=sbk, sbn=sbn, sa_o=sa[0], sa_i=sa[1],
+             sb_o=sb[0], sb_i=sb[1], sc_o=sc[0], sc_i=sc[1], M=M, N=N, K=K, ldc=ldc if ldc is not None else N, batch=batch,
+             z_inner=z_inner, accumulate=int(accumulate), alpha=float(alpha))
+
+
+def colsum(x, M, N, ld=None, out=None, scale=1.0, accumulate=False):
+    """out[n] (+)= scale * sum_m x[m*ld + n] (dig_colsum, two fixed-order stages)."""
+    t = x[0] if isinstance(x, tuple) else x
+    if out is None:
+        out = torch.empty(N, dtype=F32, device=t.device)
+    ws = torch.empty(lib().dig_colsum_chunks(M) * N, dtype=F32, device=t.device)
+    call("colsum", x=_p(x), ws=ws, out=out, M=M, ld=ld if ld is not None else N, N=N, accumulate=int(accumulate), scale=float(scale))
+    return out
+
+
+def linear_bwd(x, w, dy, M, need_dx=True):
+    """Adjoint of y = x W^T + b for x [M][K], W [N][K], dy [M][N]: -> (dx [M][K] or None, dW [N][K], db [N])."""
+    N, K = w.shape
+    dw = torch.empty(N, K, dtype=F32, device=w.device)
+    gemm_f32(dy, x, dw, N, K, M, sam=1, sak=N, sbk=K, sbn=1)          # dW[n][k] = sum_m dy[m][n] x[m][k]
+    db = colsum(dy, M, N)
+    dx = None
+    if need_dx:
+        dx = torch.empty(M, K, dtype=F32, device=w.device)
+        gemm_f32(dy, w, dx, M, K, N, sam=N, sak=1, sbk=K, sbn=1)      # dx[m][k] = sum_n dy[m][n] W[n][k]
+    return dx, dw, db
+
+
+def layernorm_bwd(x, gamma, dy, add=None, eps=1e-6):
+    """-> (dx [+ add], dgamma, dbeta) of nn.LayerNorm over the last dimension."""
+    D = x.shape[-1]
+    rows = x.numel() // D
+    nb = lib().dig_layernorm_bwd_blocks(rows)
+    part = torch.empty(nb, 2 * D, dtype=F32, device=x.device)
+    dx = torch.empty_like(x)
+    call("layernorm_bwd", x=x, gamma=gamma, dy=dy, add=add, dx=dx, part=part, rows=rows, D=D, eps=float(eps))
+    gb = colsum(part, nb, 2 * D)
+    return dx, gb[:D], gb[D:]
+
+
+def forward_train(m, img):
+    """MCTformerV2_DiG.forward without the LFCA branch (mctformer.py:227-263,293-300,318), keeping what the backward needs.
+    -> (outs {cls, pcls}, ctx)."""
+    if not img.is_cuda:
+        raise RuntimeError("dig_amd.train runs on the HIP device only (no CPU fallback)")
+    P = _pack(m)
+    B, _, H, W = img.shape
+    C, D, heads, ps = m.num_classes, m.embed_dim, m.num_heads, m.patch_embed.patch_size[0]
+    hp, wp = H // ps, W // ps
+    Pn, N = hp * wp, C + hp * wp
+    dh = D // heads
+    dev = img.device
+    img = img.contiguous().float()
+    pos = _pos_embed(m, P, H, W)
+    if pos is not P["pos"]:
+        raise NotImplementedError("dig_amd.train: the bicubic pos_embed resize (mctformer.py:210-214) has no adjoint kernel yet - "
+                                  "train at the pos_embed's own grid (224x224 for the DeiT-S checkpoint)")
+    rows = torch.empty(B * Pn, 3 * ps * ps, dtype=F32, device=dev)
+    call("patchify", img=img, rows=rows, B=B, H=H, W=W, ps=ps, flip_from=0)
+    x = torch.empty(B, N, D, dtype=F32, device=dev)
+    x[:, :C] = P["cls_pos"]
+    ops.gemm_nt(rows, P["pe_w"], (x, C * D), Pn, D, 3 * ps * ps, dtype=F32, bias=P["pe_b"], res=(pos, C * D), ldr=D,
+                batch=B, sa=(Pn * 3 * ps * ps, 0), sc=(N * D, 0), sr=(0, 0))
+    saved = []
+    for bp in P["blocks"]:
+        x0 = x
+        y1 = _layernorm(x0, bp["n1"])
+        qkv = ops.linear_rows(y1, bp["qkv"][0], bias=bp["qkv"][1])
+        S = torch.empty(B, heads, N, N, dtype=F32, device=dev)
+        gemm_f32(qkv, (qkv, D), S, N, N, dh, sam=3 * D, sak=1, sbk=1, sbn=3 * D, alpha=dh ** -0.5, batch=B * heads, z_inner=heads,
+                 sa=(N * 3 * D, dh), sb=(N * 3 * D, dh), sc=(heads * N * N, N * N))
+        Pm = ops.row_softmax(S, F32)
+        o = torch.empty(B, N, D, dtype=F32, device=dev)
+        gemm_f32(Pm, (qkv, 2 * D), o, N, dh, N, sam=N, sak=1, sbk=3 * D, sbn=1, ldc=D, batch=B * heads, z_inner=heads,
+                 sa=(heads * N * N, N * N), sb=(N * 3 * D, dh), sc=(N * D, dh))
+        x1 = ops.linear_rows(o, bp["proj"][0], bias=bp["proj"][1], res=x0)
+        y2 = _layernorm(x1, bp["n2"])
+        pre = ops.linear_rows(y2, bp["fc1"][0], bias=bp["fc1"][1])
+        hdn = torch.empty_like(pre)
+        call("act", **{"in": pre}, out=hdn, n=pre.numel(), act=1, in_f32=1, out_f32=1, dtype=1)
+        x = ops.linear_rows(hdn, bp["fc2"][0], bias=bp["fc2"][1], res=x1)
+        saved.append(dict(x0=x0, y1=y1, qkv=qkv, P=Pm, o=o, x1=x1, y2=y2, pre=pre, h=hdn))
+    head = torch.empty(B, hp, wp, C, dtype=F32, device=dev)
+    call("conv3x3", in0=x.data_ptr() + C * D * 4, in1=None, aff0=None, w=P["head"].w, bias=P["head"].bias, out=head, stats=None,
+         in0_bstride=N * D, B=B, H=hp, W=wp, C0=D, C1=0, Cout=C, groups=1, up2=0, dtype=1)
+    pcls = torch.empty(B, C, dtype=F32, device=dev)
+    call("head_pool", **{"in": head}, relu_nchw=None, pooled=pcls, B=B, P=Pn, C=C)
+    cls = torch.empty(B, C, dtype=F32, device=dev)
+    call("row_mean", x0=x, x1=None, out=cls, bstride0=N * D, bstride1=0, B=B, C=C, D=D)
+    ctx = dict(rows=rows, saved=saved, x=x, head=head, dims=(B, C, D, heads, dh, hp, wp, Pn, N, ps))
+    return {"cls": cls, "pcls": pcls}, ctx
+
+
+def backward_cls(m, outs, ctx, label, weight=1.0, grads=None):
+    """d/dparams of  weight * (F.multilabel_soft_margin_loss(cls, label) + F.multilabel_soft_margin_loss(pcls, label))
+    (model.py:337-340 with weight = W[0]; :406-409 with W[3] on the img_diff pass).  -> {named_parameters() key: gradient};
+    with `grads` given (a second pass of the same step) the new gradients are accumulated into it, as autograd's .grad does."""
+    P = _pack(m)
+    B, C, D, heads, dh, hp, wp, Pn, N, ps = ctx["dims"]
+    dev = ctx["x"].device
+    label = label.to(dev).float().contiguous()
+    M = B * N
+    new = {}
+    # ---- loss -> cls / pcls
+    dcls = torch.empty(B, C, dtype=F32, device=dev)
+    call("msm_grad", x=outs["cls"], y=label, dx=dcls, scale=float(weight) / D, B=B, C=C)       # incl. the 1/D of x_cls.mean(-1)
+    dpcls = torch.empty(B, C, dtype=F32, device=dev)
+    call("msm_grad", x=outs["pcls"], y=label, dx=dpcls, scale=float(weight), B=B, C=C)
+    # ---- top-3 pooling -> head conv (mctformer.py:298-300)
+    Cp = (C + 7) // 8 * 8
+    dhead = torch.empty(B, hp, wp, Cp, dtype=F32, device=dev)
+    call("head_pool_bwd", head=ctx["head"], dpooled=dpcls, dhead=dhead, B=B, P=Pn, C=C, Cp=Cp)
+    new["head.bias"] = colsum(dhead, B * Pn, Cp)[:C].clone()
+    # weight gradient on the zero-padded domain: a tap is then a constant element offset, dW_tap = dYpad^T Xpad[+off]
+    xfin = ctx["x"]
+    Hp2, Wp2 = hp + 2, wp + 2
+    xpad = torch.zeros(B, Hp2, Wp2, D, dtype=F32, device=dev)
+    xpad[:, 1:-1, 1:-1] = xfin[:, C:].reshape(B, hp, wp, D)
+    dypad = torch.zeros(B, Hp2, Wp2, Cp, dtype=F32, device=dev)
+    dypad[:, 1:-1, 1:-1] = dhead
+    p0 = Wp2 + 1
+    Kp = B * Hp2 * Wp2 - 2 * p0
+    dwt = torch.empty(9, Cp, D, dtype=F32, device=dev)
+    for tap in range(9):
+        off = (tap // 3 - 1) * Wp2 + (tap % 3 - 1)
+        gemm_f32((dypad, p0 * Cp), (xpad, (p0 + off) * D), (dwt, tap * Cp * D), Cp, D, Kp, sam=1, sak=Cp, sbk=D, sbn=1)
+    new["head.weight"] = dwt[:, :C].permute(1, 2, 0).reshape(C, D, 3, 3).contiguous()
+    # input gradient: the same conv kernel on dY with the taps mirrored and the channel roles swapped
+    wflip = torch.zeros(D, Cp, 3, 3, dtype=F32, device=dev)
+    wflip[:, :C] = m.head.weight.detach().float().flip(2, 3).permute(1, 0, 2, 3)
+    cwT = ops.ConvWeight(wflip, torch.zeros(D, dtype=F32, device=dev), F32)
+    dx = torch.empty(B, N, D, dtype=F32, device=dev)
+    dxp = torch.empty(B, hp, wp, D, dtype=F32, device=dev)
+    call("conv3x3", in0=dhead, in1=None, aff0=None, w=cwT.w, bias=cwT.bias, out=dxp, stats=None, in0_bstride=0, B=B, H=hp, W=wp,
+         C0=Cp, C1=0, Cout=D, groups=1, up2=0, dtype=1)
+    dx[:, C:] = dxp.reshape(B, Pn, D)
+    dx[:, :C] = dcls.unsqueeze(-1).expand(B, C, D)   # x_cls.mean(-1): every embedding element gets dcls / D (scaled above)
+    # ---- the blocks in reverse (vision_transformer.py:186-190)
+    for li in range(len(P["blocks"]) - 1, -1, -1):
+        bp, sv = P["blocks"][li], ctx["saved"][li]
+        pre = f"blocks.{li}."
+        dh_, dw, db = linear_bwd(sv["h"].reshape(M, -1), bp["fc2"][0], dx.reshape(M, D), M)
+        new[pre + "mlp.fc2.weight"], new[pre + "mlp.fc2.bias"] = dw, db
+        call("gelu_bwd", x=sv["pre"], dy=dh_, dx=dh_, n=dh_.numel())
+        dy2, dw, db = linear_bwd(sv["y2"].reshape(M, D), bp["fc1"][0], dh_, M)
+        new[pre + "mlp.fc1.weight"], new[pre + "mlp.fc1.bias"] = dw, db
+        dx1, dg, dbt = layernorm_bwd(sv["x1"], bp["n2"][0], dy2.reshape(B, N, D), add=dx)
+        new[pre + "norm2.weight"], new[pre + "norm2.bias"] = dg.clone(), dbt.clone()
+        do, dw, db = linear_bwd(sv["o"].reshape(M, D), bp["proj"][0], dx1.reshape(M, D), M)
+        new[pre + "attn.proj.weight"], new[pre + "attn.proj.bias"] = dw, db
+        # attention (vision_transformer.py:87-97): per (image, head) on the q | k | v thirds of qkv, gradients into dqkv
+        qkv, Pm = sv["qkv"], sv["P"]
+        dqkv = torch.empty(B, N, 3 * D, dtype=F32, device=dev)
+        bh = dict(batch=B * heads, z_inner=heads)
+        sq, sP, sO = (N * 3 * D, dh), (heads * N * N, N * N), (N * D, dh)
+        gemm_f32(Pm, do, (dqkv, 2 * D), N, dh, N, sam=1, sak=N, sbk=D, sbn=1, ldc=3 * D, sa=sP, sb=sO, sc=sq, **bh)            # dV = P^T dO
+        dP = torch.empty(B, heads, N, N, dtype=F32, device=dev)
+        gemm_f32(do, (qkv, 2 * D), dP, N, N, dh, sam=D, sak=1, sbk=1, sbn=3 * D, sa=sO, sb=sq, sc=sP, **bh)                    # dP = dO V^T
+        call("softmax_bwd", p=Pm, dp=dP, rows=B * heads * N, n=N, scale=dh ** -0.5)                                               # dS (of q k^T)
+        gemm_f32(dP, (qkv, D), dqkv, N, dh, N, sam=N, sak=1, sbk=3 * D, sbn=1, ldc=3 * D, sa=sP, sb=sq, sc=sq, **bh)            # dQ = dS K
+        gemm_f32(dP, qkv, (dqkv, D), N, dh, N, sam=1, sak=N, sbk=3 * D, sbn=1, ldc=3 * D, sa=sP, sb=sq, sc=sq, **bh)            # dK = dS^T Q
+        dy1, dw, db = linear_bwd(sv["y1"].reshape(M, D), bp["qkv"][0], dqkv.reshape(M, 3 * D), M)
+        new[pre + "attn.qkv.weight"], new[pre + "attn.qkv.bias"] = dw, db
+        dx, dg, dbt = layernorm_bwd(sv["x0"], bp["n1"][0], dy1.reshape(B, N, D), add=dx1)
+        new[pre + "norm1.weight"], new[pre + "norm1.bias"] = dg.clone(), dbt.clone()
+    # ---- embedding (mctformer.py:229-234): pos_embed and cls_token see the batch sum, the patch projection is a Linear
+    gp = colsum(dx, B, N * D).reshape(1, N, D)
+    new["pos_embed"] = gp
+    new["cls_token"] = gp[:, :C].clone()
+    dpatch = dx[:, C:].reshape(B * Pn, D).contiguous()
+    _, dw, db = linear_bwd(ctx["rows"], P["pe_w"], dpatch, B * Pn, need_dx=False)
+    new["patch_embed.proj.weight"] = dw.reshape(m.patch_embed.proj.weight.shape)
+    new["patch_embed.proj.bias"] = db
+    if grads is None:
+        return new
+    for k, g in new.items():
+        if k in grads:
+            _add_into(grads[k], g)
+        else:
+            grads[k] = g
+    return grads
+
+
+def _add_into(dst, src):
+    """dst += src on the device (a one-row dig_colsum with accumulate: out[n] += x[0][n])."""
+    n = dst.numel()
+    ws = torch.empty(n, dtype=F32, device=dst.device)
+    call("colsum", x=src.contiguous(), ws=ws, out=dst, M=1, ld=n, N=n, accumulate=1, scale=1.0)
+
+
+def no_weight_decay(name, p):
+    """timm.optim.optim_factory.add_weight_decay as create_optimizer applies it (model.py:244): 1-D parameters, biases and the
+    model's no_weight_decay() set {pos_embed, cls_token} are not decayed."""
+    return p.ndim <= 1 or name.endswith(".bias") or name in ("pos_embed", "cls_token")
+
+
+class AdamW:
+    """torch.optim.AdamW's update on dig_adamw, one launch per parameter tensor; state (exp_avg, exp_avg_sq, step) per name.
+    Defaults are the reference's: lr = 5e-4 * batch / 512 (model.py:241-242), weight decay 0.05, betas (0.9, 0.999), eps 1e-8
+    (train_trm.py:121-129)."""
+
+    def __init__(self, model, lr, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8):
+        self.model, self.lr, self.wd, self.betas, self.eps = model, float(lr), float(weight_decay), betas, float(eps)
+        self.state = {}
+        self.t = 0
+
+    def step(self, grads):
+        self.t += 1
+        b1, b2 = self.betas
+        bc1, bc2 = 1.0 - b1 ** self.t, 1.0 - b2 ** self.t
+        params = dict(self.model.named_parameters())
+        for k, g in grads.items():
+            p = params[k]
+            if p.dtype != F32 or not p.is_contiguous():
+                raise RuntimeError(f"AdamW: parameter {k} must be a contiguous fp32 tensor")
+            st = self.state.get(k)
+            if st is None:
+                st = self.state[k] = (torch.zeros_like(p.data), torch.zeros_like(p.data))
+            g = g.reshape(p.shape).contiguous()
+            call("adamw", p=p.data, g=g, m=st[0], v=st[1], n=p.numel(), lr=self.lr, wd=0.0 if no_weight_decay(k, p) else self.wd,
+                 beta1=b1, beta2=b2, eps=self.eps, step_size=self.lr / bc1, sqrt_bc2=math.sqrt(bc2))
+        # the kernels wrote p.data behind torch's version counters: drop the packed copies of the weights
+        self.model._packed = None
+        if hasattr(self.model, "_packed_lfca"):
+            self.model._packed_lfca = None
+
+
+def update_cls_step(m, opt, img, label, W0=1.0, img_diff=None, W3=1.0):
+    """One optimiser step on loss_cls (+ loss_cls_diff when img_diff is given): zero_grad, forward, backward, step
+    (model.py:319-341,396-410,424-425).  -> (loss_trm as a device scalar, grads)."""
+    from .losses import _msm
+    outs, ctx = forward_train(m, img)
+    dev = img.device
+    lab = label.to(dev).float().contiguous()
+    loss = torch.zeros(1, dtype=F32, device=dev)
+    _msm(outs["cls"], lab, loss, W0, False)
+    _msm(outs["pcls"], lab, loss, W0, True)
+    grads = backward_cls(m, outs, ctx, lab, W0)
+    del ctx
+    if img_diff is not None:
+        outs2, ctx2 = forward_train(m, img_diff)
+        _msm(outs2["cls"], lab, loss, W3, True)
+        _msm(outs2["pcls"], lab, loss, W3, True)
+        grads = backward_cls(m, outs2, ctx2, lab, W3, grads=grads)
+    opt.step(grads)
+    return loss, grads

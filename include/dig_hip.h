@@ -603,6 +603,111 @@ typedef struct {
 } dig_cast_args;
 int dig_cast(const dig_cast_args* a, void* stream);
 
+/* ==== (f)-4: backward of the classification losses through the MCTformer, and the optimiser step ============================
+ * model_WSSS.update: loss_trm.backward(); self.opt_trm.step()  (models/model_ECCV24_DiG.py:424-425) for the terms
+ * loss_cls / loss_cls_diff (:337-340, :406-409).  The reference leaves the backward to autograd; these are the adjoints of the
+ * forward operators of vision_transformer.py:54-103,177-196 and mctformer.py:227-300, composed by dig_amd/train.py.  fp32. */
+
+/* C[z][m*ldc + n] = alpha * sum_k A[z][m*sam + k*sak] * B[z][k*sbk + n*sbn]  (+ bias[n]) (+ the old C if accumulate),
+ * batch index z = zo*z_inner + zi with an (outer, inner) element stride pair per operand.  The adjoints of nn.Linear
+ * (vision_transformer.py:63-69,85-101: dX = dY W, dW = dY^T X) and of the two attention products (:92-97: dV = P^T dO,
+ * dP = dO V^T, dQ = dS K, dK = dS^T Q) are each one call on the tensors where they lie - a transposed operand is a stride pair. */
+typedef struct {
+    const float* a;
+    const float* b;
+    float* c;
+    const float* bias;
+    long long sam, sak, sbk, sbn;
+    long long sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
+    int M, N, K, ldc, batch, z_inner, accumulate;
+    float alpha;
+} dig_gemm_f32_args;
+int dig_gemm_f32(const dig_gemm_f32_args* a, void* stream);
+
+/* adjoint of nn.LayerNorm (vision_transformer.py:186,189 norm1 / norm2, eps 1e-6): x, dy [rows][D] ->
+ *   dx = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)) + add   (add: NULL or [rows][D], the residual path's gradient)
+ *   part [dig_layernorm_bwd_blocks(rows)][2][D]: per-row-block sums of dy*xhat (dgamma) and dy (dbeta); dig_colsum finishes them. */
+typedef struct {
+    const float* x;
+    const float* gamma;
+    const float* dy;
+    const float* add;
+    float* dx;
+    float* part;
+    long long rows;
+    int D;
+    float eps;
+} dig_layernorm_bwd_args;
+int dig_layernorm_bwd_blocks(long long rows);
+int dig_layernorm_bwd(const dig_layernorm_bwd_args* a, void* stream);
+
+/* out[n] (+)= scale * sum_m x[m*ld + n], n < N: bias gradients of nn.Linear / Conv2d, the LayerNorm partials, and the batch sum
+ * of the pos_embed / cls_token gradients (mctformer.py:231-234).  ws: [dig_colsum_chunks(M)][N] floats of workspace.
+ * Two fixed-order stages, no atomics. */
+typedef struct {
+    const float* x;
+    float* ws;
+    float* out;
+    long long M, ld;
+    int N, accumulate;
+    float scale;
+} dig_colsum_args;
+int dig_colsum_chunks(long long M);
+int dig_colsum(const dig_colsum_args* a, void* stream);
+
+/* adjoint of nn.GELU (erf form, vision_transformer.py:64): dx = dy * (Phi(x) + x*phi(x)); x = the fc1 output; dx may alias dy */
+typedef struct {
+    const float* x;
+    const float* dy;
+    float* dx;
+    long long n;
+} dig_gelu_bwd_args;
+int dig_gelu_bwd(const dig_gelu_bwd_args* a, void* stream);
+
+/* adjoint of attn.softmax(dim=-1) of the scaled logits (vision_transformer.py:93-94), in place over dp [rows][n]:
+ *   dp <- scale * p * (dp - sum_j p_j dp_j)   (scale = head_dim^-0.5, so the result is the gradient of q k^T itself) */
+typedef struct {
+    const float* p;
+    float* dp;
+    long long rows;
+    int n;
+    float scale;
+} dig_softmax_bwd_args;
+int dig_softmax_bwd(const dig_softmax_bwd_args* a, void* stream);
+
+/* dx[b][c] = scale * d/dx F.multilabel_soft_margin_loss(x, y) = scale * (sigmoid(x) - y) / (B*C)   (model.py:337-340,406-409) */
+typedef struct {
+    const float* x;
+    const float* y;
+    float* dx;
+    float scale;
+    int B, C;
+} dig_msm_grad_args;
+int dig_msm_grad(const dig_msm_grad_args* a, void* stream);
+
+/* adjoint of the top-3 pooled patch logits (mctformer.py:300): head [B][P][C] (the head conv's output, pre-ReLU), dpooled [B][C]
+ * -> dhead [B][P][Cp] (Cp >= C: channel count padded for the conv kernels; written in full, zero where nothing flows). */
+typedef struct {
+    const float* head;
+    const float* dpooled;
+    float* dhead;
+    int B, P, C, Cp;
+} dig_head_pool_bwd_args;
+int dig_head_pool_bwd(const dig_head_pool_bwd_args* a, void* stream);
+
+/* one torch.optim.AdamW update of one parameter tensor (opt_trm.step(), model.py:425; timm's create_optimizer('adamw')):
+ *   p *= 1 - lr*wd;  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  p -= step_size * m / (sqrt(v)/sqrt_bc2 + eps)
+ * with step_size = lr / (1 - b1^t), sqrt_bc2 = sqrt(1 - b2^t) formed by the caller for step t. */
+typedef struct {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    long long n;
+    float lr, wd, beta1, beta2, eps, step_size, sqrt_bc2;
+} dig_adamw_args;
+int dig_adamw(const dig_adamw_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

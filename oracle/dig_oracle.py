@@ -470,6 +470,47 @@ def mctformer_outputs(sd, img, feat_diff=None, n_layers=12):
     return out
 
 
+
+# --------------------------------------------------------------------------------------
+# (f)-4: backward of the classification losses through the MCTformer + the AdamW step (model.py:337-341,406-410,424-425)
+# --------------------------------------------------------------------------------------
+def mct_cls_loss(sd, img, label, w0=1.0):
+    """loss_cls of model_WSSS.update (model.py:337-340) - also the form of loss_cls_diff (:406-409) on the reconstructed
+    image: W * (multilabel_soft_margin(cls) + multilabel_soft_margin(pcls)) of one MCTformer pass without the LFCA branch."""
+    o = mctformer_outputs(sd, img)
+    return w0 * (F.multilabel_soft_margin_loss(o["cls"], label) + F.multilabel_soft_margin_loss(o["pcls"], label))
+
+
+def mct_cls_loss_grads(sd, img, label, w0=1.0):
+    """loss_trm.backward() (model.py:424) restricted to the loss_cls term, by autograd over this file's own forward
+    restatement: -> (loss, {state_dict key: gradient}) for every parameter the loss reaches (eval mode: no DropPath)."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
+    with torch.enable_grad():
+        loss = mct_cls_loss(leaves, img, label, w0)
+        names = [k for k in leaves]
+        grads = torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)
+    return float(loss.detach()), {k: g for k, g in zip(names, grads) if g is not None}
+
+
+def adamw_no_decay(name, p):
+    """timm.optim.create_optimizer's weight-decay filter (optim_factory.add_weight_decay, timm 0.3.x - the version the DiG
+    repo pins; timm itself is not importable here, so this is a restatement of its published rule and PARITY UNPINNED on
+    that rule): 1-D parameters, names ending in .bias, and the model's no_weight_decay() set {pos_embed, cls_token} get
+    weight_decay = 0."""
+    return p.ndim <= 1 or name.endswith(".bias") or name in ("pos_embed", "cls_token")
+
+
+def adamw_step(p, g, m, v, step, lr, wd, beta1=0.9, beta2=0.999, eps=1e-8):
+    """One torch.optim.AdamW update (decoupled decay first, bias-corrected moments, eps added to sqrt(v_hat)); `step` is the
+    1-based count after this update.  Returns (p, m, v)."""
+    p = p * (1.0 - lr * wd)
+    m = beta1 * m + (1.0 - beta1) * g
+    v = beta2 * v + (1.0 - beta2) * g * g
+    bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
+    denom = v.sqrt() / math.sqrt(bc2) + eps
+    return p - (lr / bc1) * (m / denom), m, v
+
+
 def update_forward(sd_diffusion, sd_mct, img, noises, n_layers=12):
     """Forward part of model_WSSS.update, model.py:286-322 (guidance maps -> net_trm(img, feat_diff_list)) and
     model.py:396-404 (net_trm(img_diff)), composed from the restated pieces; eval mode.

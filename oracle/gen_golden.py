@@ -13,6 +13,7 @@ Usage:  python oracle/gen_golden.py            (rewrites tests/golden/)
         python oracle/gen_golden.py keys       (only tests/golden/state_dict_keys.json)
         python oracle/gen_golden.py ddim       (only the ddim_sample_from_t cases)
         python oracle/gen_golden.py losses     (only the update() forward-loss case)
+        python oracle/gen_golden.py grads      (only the backward / AdamW case)
 """
 import json
 import os
@@ -291,6 +292,51 @@ def case_losses(mct, name, C, H, W, B, hd, wd):
     save(name, **arrays)
 
 
+def case_grads(mct, name, C, H, W, B, w0=1.0, lr=5e-4 * 32 / 512.0, wd=0.05):
+    """(f)-4: loss_cls.backward() through the REFERENCE MCTformer (eval mode: DropPath off, so it is deterministic) and one
+    torch.optim.AdamW step with timm's decay filter.  Per parameter the fixture keeps the gradient's L2 norm, its sum and 256
+    sampled entries (dig_amd.synth.sample_index), and the same sample of the updated parameter."""
+    m = mct.deit_small_MCTformerV2_DiG(num_classes=C).eval()
+    synth.fill_state_dict(m, seed=0, skip_prefixes=("norm.",))
+    sd = {k: v.clone() for k, v in m.state_dict().items() if not k.startswith(("LFCA", "diff_head_p"))}
+    img = synth.synth_imagenet_images(B, H, W, seed=6100)
+    label = synth.synth_labels(B, C, seed=13)
+    Fn = torch.nn.functional
+    with torch.enable_grad():
+        for p in m.parameters():
+            p.requires_grad_(True)
+        outs = m(img)
+        loss = w0 * (Fn.multilabel_soft_margin_loss(outs["cls"], label) + Fn.multilabel_soft_margin_loss(outs["pcls"], label))
+        loss.backward()
+    ref = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    lo, og = O.mct_cls_loss_grads(sd, img, label, w0)
+    assert set(og) == set(ref), (sorted(set(og) ^ set(ref)))
+    rel = max(float((og[k] - ref[k]).norm() / (ref[k].norm() + 1e-30)) for k in ref)
+    # one AdamW step (timm's create_optimizer('adamw'): torch-AdamW maths, no decay on 1-D / bias / pos_embed / cls_token)
+    named = [(k, p) for k, p in m.named_parameters() if p.grad is not None]
+    groups = [{"params": [p for k, p in named if O.adamw_no_decay(k, p)], "weight_decay": 0.0},
+              {"params": [p for k, p in named if not O.adamw_no_decay(k, p)], "weight_decay": wd}]
+    before = {k: p.detach().clone() for k, p in named}
+    opt = torch.optim.AdamW(groups, lr=lr, betas=(0.9, 0.999), eps=1e-8)
+    opt.step()
+    arrays = {"label": label, "loss": np.float64(float(loss)), "lr": np.float64(lr), "wd": np.float64(wd)}
+    names = sorted(ref)
+    arrays["names"] = np.array(names)
+    drel = 0.0
+    for i, k in enumerate(names):
+        idx = synth.sample_index(k, ref[k].numel())
+        arrays[f"g{i}_norm"] = np.float64(float(ref[k].double().norm()))
+        arrays[f"g{i}_sum"] = np.float64(float(ref[k].double().sum()))
+        arrays[f"g{i}_s"] = ref[k].flatten()[idx]
+        newp = dict(named)[k].detach()
+        arrays[f"p{i}_s"] = newp.flatten()[idx]
+        po, _, _ = O.adamw_step(before[k], ref[k], torch.zeros_like(ref[k]), torch.zeros_like(ref[k]), 1, lr,
+                                0.0 if O.adamw_no_decay(k, before[k]) else wd)
+        drel = max(drel, float((po - newp).abs().max() / lr))
+    record(name, loss=abs(lo - float(loss)), grad_rel=rel, adamw_update_over_lr=drel)
+    save(name, **arrays)
+
+
 def synth_eval_set(C=20, seed=5):
     """Small synthetic CAM dicts + ground-truth maps (with 255 boundary pixels) for the evaluation cases."""
     rng = np.random.RandomState(seed)
@@ -422,6 +468,10 @@ def main():
         case_cam(mct, "cam368x496_c20", 20, 368, 496, 1)
         _merge_manifest()
         return
+    if sys.argv[1:] == ["grads"]:  # (f)-4: the reference's own .grad tensors (sampled) + one AdamW step
+        case_grads(mct, "grads224_c20", 20, 224, 224, 2)
+        _merge_manifest()
+        return
     if sys.argv[1:] == ["eval"]:
         case_eval(ref_import.load_evaluation())
         _merge_manifest()
@@ -438,6 +488,7 @@ def main():
     case_cam(mct, "cam224_c80", 80, 224, 224, 1)
     case_cam(mct, "cam368x496_c20", 20, 368, 496, 1)
     case_envelope_full(ddp, "unet256_t100_img0", 256, 256, 0)
+    case_grads(mct, "grads224_c20", 20, 224, 224, 2)
     case_lfca(mct, "lfca224_c20", 20, 224, 224, 14, 14)
     case_lfca(mct, "lfca224_c20_maps16", 20, 224, 224, 16, 16)  # guidance maps from a 256x256 diffusion input: bilinear 14 -> 16
     case_eval(ref_import.load_evaluation())

@@ -1,0 +1,211 @@
+"""GPU tier (-m gpu): the training step of the MCTformer classification losses (model.py:337-341,406-410,
+424-425) on the adjoint kernels of csrc/train.hip, all through the C ABI.
+
+ * every adjoint kernel against torch autograd of the forward operator it inverts (fp32, tolerances in each test);
+ * the whole backward against tests/golden/grads224_c20.npz - the REFERENCE's own .grad tensors (oracle/gen_golden.py grads:
+   reference MCTformer in eval mode, so DropPath is off and the result deterministic), kept as L2 norm, sum and 256 sampled
+   entries per parameter - and, tensor by tensor, against autograd over the CPU oracle's forward restatement;
+ * one AdamW step against the fixture's updated parameters (torch.optim.AdamW with timm's no-decay filter);
+ * a step is bitwise reproducible.
+Tolerance of the end-to-end gradients: 1e-4 relative L2 per tensor, 1e-4 * max|g| + 1e-8 on the sampled entries (fp32
+reassociation through twelve blocks; measured 4e-7 / 2e-6, printed)."""
+import numpy as np
+import pytest
+import torch
+
+import dig_oracle as O
+from dig_amd import synth, train
+from dig_amd._lib import call
+from dig_amd.mctformer import create_model
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+F32 = torch.float32
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def make_mct(C):
+    m = create_model("deit_small_MCTformerV2_DiG", pretrained=False, num_classes=C, drop_rate=0.0, drop_path_rate=0.0, drop_block_rate=None, lfca=False)
+    synth.fill_state_dict(m, seed=0, skip_prefixes=("norm.",))
+    return m.to(DEV).eval()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+@pytest.mark.parametrize("M,N,K", [(37, 50, 19), (128, 64, 16), (216, 64, 216), (300, 130, 77)])
+def test_gemm_f32_stride_forms(M, N, K):
+    """all four transposition forms + bias + alpha + accumulate against torch.matmul (fp32 MFMA is exact fp32 arithmetic: the
+    difference is summation order only; bound 1e-5 * K^0.5 * scale)."""
+    with torch.no_grad():
+        a, b, bias = rnd(M, K, seed=1), rnd(K, N, seed=2), rnd(N, seed=3)
+        ref = 0.7 * (a @ b) + bias
+        tol = 2e-6 * K * float(ref.abs().max())
+        for ta in (False, True):
+            for tb in (False, True):
+                A = a.t().contiguous() if ta else a
+                B = b.t().contiguous() if tb else b
+                c = torch.empty(M, N, device=DEV)
+                train.gemm_f32(A, B, c, M, N, K, sam=1 if ta else K, sak=M if ta else 1, sbk=1 if tb else N, sbn=K if tb else 1, bias=bias, alpha=0.7)
+                assert float((c - ref).abs().max()) <= tol, (ta, tb)
+        c0 = rnd(M, N + 3, seed=4)
+        c = c0.clone()
+        train.gemm_f32(a, b, c, M, N, K, sam=K, sak=1, sbk=N, sbn=1, ldc=N + 3, accumulate=True)
+        assert float((c[:, :N] - (c0[:, :N] + a @ b)).abs().max()) <= tol and torch.equal(c[:, N:], c0[:, N:])
+
+
+def test_gemm_f32_batched_attention_layout():
+    """the (image, head) batching on the q | k | v thirds of a qkv buffer, as forward_train / backward_cls use it"""
+    with torch.no_grad():
+        B, H, N, dh = 2, 3, 45, 64
+        D = H * dh
+        qkv = rnd(B, N, 3 * D, seed=5)
+        q, k, v = qkv.reshape(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
+        S = torch.empty(B, H, N, N, device=DEV)
+        train.gemm_f32(qkv, (qkv, D), S, N, N, dh, sam=3 * D, sak=1, sbk=1, sbn=3 * D, alpha=0.125, batch=B * H, z_inner=H,
+                       sa=(N * 3 * D, dh), sb=(N * 3 * D, dh), sc=(H * N * N, N * N))
+        assert float((S - 0.125 * q @ k.transpose(-1, -2)).abs().max()) <= 1e-4
+        P = S.softmax(-1)
+        dO = rnd(B, N, D, seed=6)
+        dqkv = torch.zeros(B, N, 3 * D, device=DEV)
+        train.gemm_f32(P, dO, (dqkv, 2 * D), N, dh, N, sam=1, sak=N, sbk=D, sbn=1, ldc=3 * D, batch=B * H, z_inner=H,
+                       sa=(H * N * N, N * N), sb=(N * D, dh), sc=(N * 3 * D, dh))
+        dv = (P.transpose(-1, -2) @ dO.reshape(B, N, H, dh).permute(0, 2, 1, 3)).permute(0, 2, 1, 3).reshape(B, N, D)
+        assert float((dqkv[..., 2 * D:] - dv).abs().max()) <= 1e-4 and float(dqkv[..., :2 * D].abs().max()) == 0.0
+
+
+def test_layernorm_gelu_softmax_adjoints():
+    x = rnd(70, 384, seed=7).requires_grad_(True)
+    g, b = rnd(384, seed=8).requires_grad_(True), rnd(384, seed=9).requires_grad_(True)
+    dy, add = rnd(70, 384, seed=10), rnd(70, 384, seed=11)
+    y = torch.nn.functional.layer_norm(x, (384,), g, b, 1e-6)
+    y.backward(dy)
+    with torch.no_grad():
+        dx, dg, db = train.layernorm_bwd(x.detach(), g.detach(), dy, add=add)
+        assert float((dx - (x.grad + add)).abs().max()) <= 2e-5 * float(x.grad.abs().max() + 1)
+        assert float((dg - g.grad).abs().max()) <= 1e-4 and float((db - b.grad).abs().max()) <= 1e-4
+    x = rnd(50, 1536, seed=12, scale=2.0).requires_grad_(True)
+    dy = rnd(50, 1536, seed=13)
+    torch.nn.functional.gelu(x).backward(dy)
+    with torch.no_grad():
+        dx = torch.empty_like(dy)
+        call("gelu_bwd", x=x.detach(), dy=dy, dx=dx, n=dy.numel())
+        assert float((dx - x.grad).abs().max()) <= 2e-6
+    s = rnd(33, 216, seed=14, scale=3.0).requires_grad_(True)
+    dp = rnd(33, 216, seed=15)
+    p = (s * 0.125).softmax(-1)
+    p.backward(dp)
+    with torch.no_grad():
+        d = dp.clone()
+        call("softmax_bwd", p=p.detach(), dp=d, rows=33, n=216, scale=0.125)
+        assert float((d - s.grad).abs().max()) <= 1e-6
+
+
+def test_head_pool_and_msm_adjoints():
+    B, P, C = 3, 196, 20
+    head = rnd(B, P, C, seed=16).requires_grad_(True)
+    hv = head.permute(0, 2, 1)
+    top = lambda t: torch.topk(t, dim=-1, k=3)[0].mean(-1)
+    pooled = top(torch.relu(hv)) - top(torch.relu(-hv))
+    y = (rnd(B, C, seed=17) > 0).float()
+    loss = 1.3 * torch.nn.functional.multilabel_soft_margin_loss(pooled, y)
+    loss.backward()
+    with torch.no_grad():
+        dpool = torch.empty(B, C, device=DEV)
+        call("msm_grad", x=pooled.detach(), y=y, dx=dpool, scale=1.3, B=B, C=C)
+        dhead = torch.full((B, P, 24), 7.0, device=DEV)
+        call("head_pool_bwd", head=head.detach(), dpooled=dpool, dhead=dhead, B=B, P=P, C=C, Cp=24)
+        assert float(dhead[..., C:].abs().max()) == 0.0
+        assert float((dhead[..., :C] - head.grad).abs().max()) <= 1e-7
+
+
+def _grads(B=2, seed=6100):
+    m = make_mct(20)
+    img = synth.synth_imagenet_images(B, 224, 224, seed=seed).to(DEV)
+    label = synth.synth_labels(B, 20, seed=13)
+    with torch.no_grad():
+        outs, ctx = train.forward_train(m, img)
+        g = train.backward_cls(m, outs, ctx, label.to(DEV), 1.0)
+    return m, img, label, outs, g
+
+
+def test_backward_vs_reference_grads(golden):
+    fx = golden("grads224_c20")
+    m, img, label, outs, g = _grads()
+    assert np.array_equal(label.numpy(), fx["label"])
+    names = [str(n) for n in fx["names"]]
+    assert set(names) == set(g), sorted(set(names) ^ set(g))
+    params = dict(m.named_parameters())
+    worst_rel, worst_samp = 0.0, 0.0
+    for i, k in enumerate(names):
+        gk = g[k].reshape(params[k].shape).float().cpu()
+        idx = synth.sample_index(k, gk.numel())
+        rs, rn = T(fx[f"g{i}_s"]), float(fx[f"g{i}_norm"])
+        samp = float((gk.flatten()[idx] - rs).abs().max())
+        scale = float(rs.abs().max())
+        dn = abs(float(gk.double().norm()) - rn) / (rn + 1e-30)
+        dsum = abs(float(gk.double().sum()) - float(fx[f"g{i}_sum"]))
+        worst_rel, worst_samp = max(worst_rel, dn), max(worst_samp, samp / (scale + 1e-12))
+        assert dn <= 1e-4, (k, dn)
+        assert samp <= 1e-4 * scale + 1e-8, (k, samp, scale)
+        assert dsum <= 1e-4 * rn * gk.numel() ** 0.5 + 1e-6, (k, dsum)
+    print("backward vs reference .grad: worst relative norm error", worst_rel, "worst sampled-entry error / max", worst_samp)
+    # tensor by tensor against autograd over the CPU oracle's forward
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    lo, og = O.mct_cls_loss_grads(sd, img.cpu(), label, 1.0)
+    assert abs(lo - float(fx["loss"])) <= 1e-6
+    worst = 0.0
+    for k in names:
+        gk = g[k].reshape(og[k].shape).cpu()
+        rel = float((gk - og[k]).norm() / (og[k].norm() + 1e-30))
+        worst = max(worst, rel)
+        assert rel <= 1e-4, (k, rel)
+    print("backward vs oracle autograd: worst relative L2 error over", len(names), "tensors:", worst)
+
+
+def test_adamw_step_vs_reference(golden):
+    fx = golden("grads224_c20")
+    m, img, label, outs, g = _grads()
+    lr, wd = float(fx["lr"]), float(fx["wd"])
+    before = {k: p.detach().clone() for k, p in m.named_parameters()}
+    opt = train.AdamW(m, lr=lr, weight_decay=wd)
+    with torch.no_grad():
+        opt.step(g)
+    names = [str(n) for n in fx["names"]]
+    worst = 0.0
+    params = dict(m.named_parameters())
+    for i, k in enumerate(names):
+        p = params[k].detach().cpu()
+        idx = synth.sample_index(k, p.numel())
+        diff = (p.flatten()[idx] - T(fx[f"p{i}_s"])).abs()
+        # the first Adam step moves an entry by lr * g / (|g| + eps): ~lr * sign(g) wherever |g| >> eps = 1e-8, so a wrong sign
+        # or a missing decay shows as >= lr there.  Entries whose gradient is numerical noise around an exact zero (the key
+        # bias: softmax is invariant to it) move by noise / (noise + eps) and are only bounded by lr.
+        solid = T(fx[f"g{i}_s"]).abs() > 1e-5
+        d = float(diff[solid].max()) if bool(solid.any()) else 0.0
+        worst = max(worst, d / lr)
+        assert d <= 0.05 * lr, (k, d, lr)
+        assert float(diff.max()) <= 2.0 * lr + 1e-9, (k, float(diff.max()))
+        assert float((p - before[k].cpu()).abs().max()) > 0.0
+    print("AdamW: worst |p - reference| / lr over the sampled entries:", worst)
+    assert m._packed is None  # the packed weight copies are dropped: the next forward re-packs from the updated parameters
+    with torch.no_grad():
+        o2, _ = train.forward_train(m, img)
+    assert not torch.equal(o2["cls"], outs["cls"])
+
+
+def test_training_step_is_bitwise_reproducible_and_accumulates():
+    m, img, label, outs, g1 = _grads()
+    _, _, _, _, g2 = _grads()
+    assert all(torch.equal(g1[k], g2[k]) for k in g1)
+    # a second pass accumulates like autograd's .grad: loss_cls + loss_cls_diff on the same image with weights 1 and 0.5
+    with torch.no_grad():
+        o, ctx = train.forward_train(m, img)
+        acc = train.backward_cls(m, o, ctx, label.to(DEV), 0.5, grads={k: v.clone() for k, v in g1.items()})
+    for k in g1:
+        assert float((acc[k] - 1.5 * g1[k]).abs().max()) <= 1e-5 * float(g1[k].abs().max()) + 1e-9, k

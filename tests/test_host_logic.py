@@ -45,6 +45,33 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert L.dig_gemm_nt(ctypes.byref(a), None) == -1 and b"null pointer" in L.dig_last_error()
     c = _lib.STRUCTS["dig_conv3x3_args"]()
     assert L.dig_conv3x3(ctypes.byref(c), None) == -1
+    for fn in ("gemm_f32", "layernorm_bwd", "colsum", "gelu_bwd", "softmax_bwd", "msm_grad", "head_pool_bwd", "adamw"):
+        st = _lib.STRUCTS[f"dig_{fn}_args"]()
+        assert getattr(L, f"dig_{fn}")(ctypes.byref(st), None) == -1, fn
+    assert L.dig_layernorm_bwd_blocks(ctypes.c_longlong(33)) == 2 and L.dig_colsum_chunks(ctypes.c_longlong(129)) == 2
+
+
+def test_adamw_rule_and_decay_filter():
+    """The optimiser restatements against torch.optim.AdamW itself (CPU): oracle formula = torch's update; the product's
+    no-decay filter = the oracle's (timm's add_weight_decay rule: 1-D, .bias, pos_embed, cls_token)."""
+    import dig_oracle as O
+    from dig_amd import train
+    torch.manual_seed(3)
+    p0, g = torch.randn(7, 5), torch.randn(7, 5)
+    q = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([q], lr=1e-3, weight_decay=0.05)
+    m, v, p = torch.zeros_like(p0), torch.zeros_like(p0), p0.clone()
+    for t in (1, 2, 3):
+        q.grad = g * t
+        opt.step()
+        p, m, v = O.adamw_step(p, g * t, m, v, t, 1e-3, 0.05)
+        assert float((p - q.detach()).abs().max()) <= 1e-6
+    net = create_model("deit_small_MCTformerV2_DiG", pretrained=False, num_classes=20, lfca=False)
+    for k, prm in net.named_parameters():
+        assert train.no_weight_decay(k, prm) == O.adamw_no_decay(k, prm), k
+    nd = {k for k, prm in net.named_parameters() if train.no_weight_decay(k, prm)}
+    assert {"pos_embed", "cls_token", "head.bias", "blocks.0.norm1.weight", "blocks.3.attn.qkv.bias"} <= nd
+    assert "blocks.0.attn.qkv.weight" not in nd and "head.weight" not in nd and "patch_embed.proj.weight" not in nd
 
 
 def test_state_dict_keys_and_no_cpu_fallback():

@@ -155,6 +155,34 @@ def test_lfca_consumer(golden):
         assert (o[k] - T(g[k])).abs().max() <= TOL, k
 
 
+def test_backward_and_adamw_vs_reference_grads(golden):
+    """autograd over the oracle's forward restatement against the REFERENCE's own .grad tensors (sampled entries,
+    L2 norm and sum per parameter, oracle/gen_golden.py grads) and the oracle's AdamW formula against the parameters that
+    torch.optim.AdamW (timm's decay filter) produced from them."""
+    g = golden("grads224_c20")
+    m = create_model("deit_small_MCTformerV2_DiG", pretrained=False, num_classes=20, lfca=False)
+    synth.fill_state_dict(m, seed=0, skip_prefixes=("norm.",))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    img = synth.synth_imagenet_images(2, 224, 224, seed=6100)
+    label = synth.synth_labels(2, 20, seed=13)
+    assert np.array_equal(label.numpy(), g["label"])
+    loss, og = O.mct_cls_loss_grads(sd, img, label, 1.0)
+    assert abs(loss - float(g["loss"])) <= 1e-6
+    names = [str(n) for n in g["names"]]
+    assert set(names) == set(og)
+    lr, wd = float(g["lr"]), float(g["wd"])
+    for i, k in enumerate(names):
+        idx = synth.sample_index(k, og[k].numel())
+        rs = T(g[f"g{i}_s"])
+        assert float((og[k].flatten()[idx] - rs).abs().max()) <= 1e-5 * float(rs.abs().max()) + 1e-9, k
+        assert abs(float(og[k].double().norm()) - float(g[f"g{i}_norm"])) <= 1e-5 * float(g[f"g{i}_norm"]) + 1e-12, k
+        p, _, _ = O.adamw_step(sd[k], og[k], torch.zeros_like(og[k]), torch.zeros_like(og[k]), 1, lr,
+                               0.0 if O.adamw_no_decay(k, sd[k]) else wd)
+        solid = rs.abs() > 1e-5  # where the gradient is more than noise around an exact zero (the key bias)
+        if bool(solid.any()):
+            assert float((p.flatten()[idx] - T(g[f"p{i}_s"])).abs()[solid].max()) <= 0.01 * lr, k
+
+
 def _eval_set(g):
     dicts, gts = [], []
     i = 0
