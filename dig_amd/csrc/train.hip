@@ -30,10 +30,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(dig_gemm_f32_args a) {
     __shared__ float Bs[2][GBK][GPB];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hf = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int z = blockIdx.z, zo = z / a.z_inner, zi = z - zo * a.z_inner;
+    // split-K (ksplit > 1: the weight gradients - a small output summed over every token): K slice zk writes its own partial
+    // output at c + zk * sc_k; the caller adds the slices with dig_colsum (fixed order)
+    const int ks = a.ksplit > 1 ? a.ksplit : 1;
+    const int zk = blockIdx.z % ks, z = blockIdx.z / ks, zo = z / a.z_inner, zi = z - zo * a.z_inner;
+    const int kc = ((a.K + ks - 1) / ks + GBK - 1) / GBK * GBK;
+    const int k_begin = zk * kc, k_end = min(a.K, k_begin + kc);
     const float* A = a.a + (size_t)zo * a.sa_o + (size_t)zi * a.sa_i;
     const float* B = a.b + (size_t)zo * a.sb_o + (size_t)zi * a.sb_i;
-    float* C = a.c + (size_t)zo * a.sc_o + (size_t)zi * a.sc_i;
+    float* C = a.c + (size_t)zo * a.sc_o + (size_t)zi * a.sc_i + (size_t)zk * a.sc_k;
     const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
     // global -> register staging: 8 A elements and 4 B elements per thread and K tile.  The thread -> element map follows
     // the contiguous direction of each operand (uniform branch), so a wave's loads are whole 256-byte runs either way.
@@ -46,7 +51,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(dig_gemm_f32_args a) {
             if (a_kfast) { kk = tid & 15; mm = (tid >> 4) + 16 * i; }
             else { mm = (tid & 127); kk = (tid >> 7) + 2 * i; }
             const int m = m0 + mm, k = k0 + kk;
-            ra[i] = (m < a.M && k < a.K) ? A[(size_t)m * a.sam + (size_t)k * a.sak] : 0.f;
+            ra[i] = (m < a.M && k < k_end) ? A[(size_t)m * a.sam + (size_t)k * a.sak] : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -54,7 +59,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(dig_gemm_f32_args a) {
             if (b_kfast) { kk = tid & 15; nn = (tid >> 4) + 16 * i; }
             else { nn = tid & 63; kk = (tid >> 6) + 4 * i; }
             const int n = n0 + nn, k = k0 + kk;
-            rb[i] = (n < a.N && k < a.K) ? B[(size_t)k * a.sbk + (size_t)n * a.sbn] : 0.f;
+            rb[i] = (n < a.N && k < k_end) ? B[(size_t)k * a.sbk + (size_t)n * a.sbn] : 0.f;
         }
     };
     auto lstore = [&](int buf) {
@@ -78,13 +83,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(dig_gemm_f32_args a) {
     for (int j = 0; j < 2; j++)
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[j][e] = 0.f;
-    const int nk = (a.K + GBK - 1) / GBK;
-    gload(0);
+    const int nk = k_end > k_begin ? (k_end - k_begin + GBK - 1) / GBK : 0;  // an empty slice writes zeros
+    gload(k_begin);
     lstore(0);
     __syncthreads();
     for (int kt = 0; kt < nk; kt++) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * GBK);
+        if (kt + 1 < nk) gload(k_begin + (kt + 1) * GBK);
 #pragma unroll
         for (int k2 = 0; k2 < GBK / 2; k2++) {
             const float av = As[buf][2 * k2 + hf][32 * wave + r];
@@ -114,9 +119,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(dig_gemm_f32_args a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// LayerNorm backward: one wave per row, 32 rows per 256-thread block.  y = (x - mu) rstd g + b:
+// LayerNorm backward: one wave per row, 8 rows per 256-thread block (32 rows left 216 blocks for 256 CUs at B = 32: 51 us).  y = (x - mu) rstd g + b:
 //   dx = rstd (g dy - mean(g dy) - xhat mean(g dy xhat)) [+ add],  dgamma = sum_rows dy xhat,  dbeta = sum_rows dy
-constexpr int LN_ROWS = 32, LN_MAXV = 16;  // D <= 64 * LN_MAXV
+constexpr int LN_ROWS = 8, LN_MAXV = 16;  // D <= 64 * LN_MAXV
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(dig_layernorm_bwd_args a) {
     __shared__ float red[4][2][256];  // one 256-column slice of the four waves' partial sums at a time
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -199,7 +204,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(dig_layernorm_bwd_ar
 // ------------------------------------------------------------------------------------------------------------------------
 // column sums: stage 1 sums chunks of CS_ROWS rows (4 row lanes x 64 columns per block, fixed order), stage 2 the chunks
 constexpr int CS_ROWS = 128;
-__global__ __launch_bounds__(256) void colsum1_kernel(const float* x, float* ws, long long M, int N, long long ld) {
+// (direct: a single chunk - the split-K reduction, the LayerNorm partials of a small batch - goes straight to `out`)
+__global__ __launch_bounds__(256) void colsum1_kernel(const float* x, float* ws, long long M, int N, long long ld, float* out, float scale, int accumulate) {
     __shared__ float red[4][64];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
     const long long r0 = (long long)blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
@@ -208,7 +214,11 @@ __global__ __launch_bounds__(256) void colsum1_kernel(const float* x, float* ws,
         for (long long rw = r0 + rl; rw < r1; rw += 4) s += x[(size_t)rw * ld + col];
     red[rl][threadIdx.x & 63] = s;
     __syncthreads();
-    if (rl == 0 && col < N) ws[(size_t)blockIdx.y * N + col] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    if (rl == 0 && col < N) {
+        const float t = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+        if (out) out[col] = accumulate ? out[col] + t * scale : t * scale;
+        else ws[(size_t)blockIdx.y * N + col] = t;
+    }
 }
 __global__ __launch_bounds__(256) void colsum2_kernel(const float* ws, float* out, int chunks, int N, float scale, int accumulate) {
     const int col = blockIdx.x * 256 + threadIdx.x;
@@ -325,8 +335,11 @@ extern "C" int dig_gemm_f32(const dig_gemm_f32_args* a, void* stream_) {
     DIG_CHECK(a && a->a && a->b && a->c, DIG_EINVAL, "gemm_f32: null pointer");
     DIG_CHECK(a->M > 0 && a->N > 0 && a->K > 0 && a->batch > 0 && a->z_inner > 0 && a->batch % a->z_inner == 0 && a->ldc >= a->N, DIG_EINVAL,
               "gemm_f32: bad shape M=%d N=%d K=%d batch=%d z_inner=%d ldc=%d", a->M, a->N, a->K, a->batch, a->z_inner, a->ldc);
-    DIG_CHECK(a->batch <= 65535, DIG_EINVAL, "gemm_f32: batch %d > 65535", a->batch);
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(a->N, GBN), cdiv(a->M, GBM), a->batch), dim3(256), 0, stream, *a);
+    const int ks = a->ksplit > 1 ? a->ksplit : 1;
+    DIG_CHECK((long long)a->batch * ks <= 65535, DIG_EINVAL, "gemm_f32: batch %d x ksplit %d > 65535", a->batch, ks);
+    DIG_CHECK(ks == 1 || (!a->bias && !a->accumulate && a->sc_k >= (long long)a->M * a->ldc), DIG_EINVAL,
+              "gemm_f32: split-K writes plain partial outputs (no bias / accumulate) sc_k >= M*ldc elements apart");
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(a->N, GBN), cdiv(a->M, GBM), a->batch * ks), dim3(256), 0, stream, *a);
     DIG_LAUNCH_CHECK("gemm_f32");
     return DIG_OK;
 }
@@ -350,8 +363,12 @@ extern "C" int dig_colsum(const dig_colsum_args* a, void* stream_) {
     DIG_CHECK(a->M > 0 && a->N > 0 && a->ld >= a->N, DIG_EINVAL, "colsum: bad shape M=%lld N=%d ld=%lld", a->M, a->N, a->ld);
     const int chunks = dig_colsum_chunks(a->M);
     DIG_CHECK(chunks <= 65535, DIG_EINVAL, "colsum: %d row chunks > 65535", chunks);
-    hipLaunchKernelGGL(colsum1_kernel, dim3(cdiv(a->N, 64), chunks), dim3(256), 0, stream, a->x, a->ws, a->M, a->N, a->ld);
-    hipLaunchKernelGGL(colsum2_kernel, dim3(cdiv(a->N, 256)), dim3(256), 0, stream, (const float*)a->ws, a->out, chunks, a->N, a->scale, a->accumulate);
+    if (chunks == 1) {
+        hipLaunchKernelGGL(colsum1_kernel, dim3(cdiv(a->N, 64), 1), dim3(256), 0, stream, a->x, a->ws, a->M, a->N, a->ld, a->out, a->scale, a->accumulate);
+    } else {
+        hipLaunchKernelGGL(colsum1_kernel, dim3(cdiv(a->N, 64), chunks), dim3(256), 0, stream, a->x, a->ws, a->M, a->N, a->ld, (float*)nullptr, 1.0f, 0);
+        hipLaunchKernelGGL(colsum2_kernel, dim3(cdiv(a->N, 256)), dim3(256), 0, stream, (const float*)a->ws, a->out, chunks, a->N, a->scale, a->accumulate);
+    }
     DIG_LAUNCH_CHECK("colsum");
     return DIG_OK;
 }

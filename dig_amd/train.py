@@ -36,14 +36,28 @@ def _p(x):
 
 
 def gemm_f32(a, b, c, M, N, K, *, sam, sak, sbk, sbn, ldc=None, bias=None, alpha=1.0, batch=1, z_inner=1,
-             sa=(0, 0), sb=(0, 0), sc=(0, 0), accumulate=False):
+             sa=(0, 0), sb=(0, 0), sc=(0, 0), accumulate=False, ksplit=1):
     """dig_gemm_f32: C[z][m][n] = alpha * sum_k A[z][m*sam + k*sak] * B[z][k*sbk + n*sbn] (+ bias) (+ C).  a / b / c are fp32
-    tensors or (tensor, element offset); strides in elements."""
+    tensors or (tensor, element offset); strides in elements.  ksplit > 1 (batch 1, dense C): K is cut into that many slices
+    whose partial products are added by dig_colsum - the weight gradients, whose output is a few tiles and K every token."""
     t = c[0] if isinstance(c, tuple) else c
+    kw = dict(a=_p(a), b=_p(b), bias=bias, sam=sam, sak=sak, sbk=sbk, sbn=sbn, sa_o=sa[0], sa_i=sa[1], sb_o=sb[0], sb_i=sb[1],
+              sc_o=sc[0], sc_i=sc[1], M=M, N=N, K=K, ldc=ldc if ldc is not None else N, batch=batch, z_inner=z_inner,
+              accumulate=int(accumulate), alpha=float(alpha))
     with torch.cuda.device(t.device):
-        call("gemm_f32", a=_p(a), b=_p(b), c=_p(c), bias=bias, sam=sam, sak=sak, sbk=sbk, sbn=sbn, sa_o=sa[0], sa_i=sa[1],
-             sb_o=sb[0], sb_i=sb[1], sc_o=sc[0], sc_i=sc[1], M=M, N=N, K=K, ldc=ldc if ldc is not None else N, batch=batch,
-             z_inner=z_inner, accumulate=int(accumulate), alpha=float(alpha))
+        if ksplit > 1:
+            assert batch == 1 and bias is None and not accumulate and (ldc is None or ldc == N)
+            part = torch.empty(ksplit, M * N, dtype=F32, device=t.device)
+            call("gemm_f32", c=part, sc_k=M * N, ksplit=ksplit, **kw)
+            colsum(part, ksplit, M * N, out=c)
+        else:
+            call("gemm_f32", c=_p(c), sc_k=0, ksplit=1, **kw)
+
+
+def _ksplit(M, N, K):
+    """K slices for a small-output product: about two blocks per CU (128 x 64 tiles), at least 64 K values per slice."""
+    tiles = ((M + 127) // 128) * ((N + 63) // 64)
+    return max(1, min(64, 512 // tiles, K // 64))
 
 
 def colsum(x, M, N, ld=None, out=None, scale=1.0, accumulate=False):
@@ -52,7 +66,7 @@ def colsum(x, M, N, ld=None, out=None, scale=1.0, accumulate=False):
     if out is None:
         out = torch.empty(N, dtype=F32, device=t.device)
     ws = torch.empty(lib().dig_colsum_chunks(M) * N, dtype=F32, device=t.device)
-    call("colsum", x=_p(x), ws=ws, out=out, M=M, ld=ld if ld is not None else N, N=N, accumulate=int(accumulate), scale=float(scale))
+    call("colsum", x=_p(x), ws=ws, out=_p(out), M=M, ld=ld if ld is not None else N, N=N, accumulate=int(accumulate), scale=float(scale))
     return out
 
 
@@ -60,7 +74,7 @@ def linear_bwd(x, w, dy, M, need_dx=True):
     """Adjoint of y = x W^T + b for x [M][K], W [N][K], dy [M][N]: -> (dx [M][K] or None, dW [N][K], db [N])."""
     N, K = w.shape
     dw = torch.empty(N, K, dtype=F32, device=w.device)
-    gemm_f32(dy, x, dw, N, K, M, sam=1, sak=N, sbk=K, sbn=1)          # dW[n][k] = sum_m dy[m][n] x[m][k]
+    gemm_f32(dy, x, dw, N, K, M, sam=1, sak=N, sbk=K, sbn=1, ksplit=_ksplit(N, K, M))   # dW[n][k] = sum_m dy[m][n] x[m][k]
     db = colsum(dy, M, N)
     dx = None
     if need_dx:
@@ -166,7 +180,8 @@ def backward_cls(m, outs, ctx, label, weight=1.0, grads=None):
     dwt = torch.empty(9, Cp, D, dtype=F32, device=dev)
     for tap in range(9):
         off = (tap // 3 - 1) * Wp2 + (tap % 3 - 1)
-        gemm_f32((dypad, p0 * Cp), (xpad, (p0 + off) * D), (dwt, tap * Cp * D), Cp, D, Kp, sam=1, sak=Cp, sbk=D, sbn=1)
+        gemm_f32((dypad, p0 * Cp), (xpad, (p0 + off) * D), (dwt, tap * Cp * D), Cp, D, Kp, sam=1, sak=Cp, sbk=D, sbn=1,
+                 ksplit=_ksplit(Cp, D, Kp))
     new["head.weight"] = dwt[:, :C].permute(1, 2, 0).reshape(C, D, 3, 3).contiguous()
     # input gradient: the same conv kernel on dY with the taps mirrored and the channel roles swapped
     wflip = torch.zeros(D, Cp, 3, 3, dtype=F32, device=dev)

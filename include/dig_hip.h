@@ -619,7 +619,8 @@ typedef struct {
     const float* bias;
     long long sam, sak, sbk, sbn;
     long long sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
-    int M, N, K, ldc, batch, z_inner, accumulate;
+    long long sc_k; /* ksplit > 1: K slice s writes its partial product at c + s*sc_k (no bias / accumulate); dig_colsum adds them */
+    int M, N, K, ldc, batch, z_inner, accumulate, ksplit;
     float alpha;
 } dig_gemm_f32_args;
 int dig_gemm_f32(const dig_gemm_f32_args* a, void* stream);

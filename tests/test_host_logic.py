@@ -48,7 +48,7 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     for fn in ("gemm_f32", "layernorm_bwd", "colsum", "gelu_bwd", "softmax_bwd", "msm_grad", "head_pool_bwd", "adamw"):
         st = _lib.STRUCTS[f"dig_{fn}_args"]()
         assert getattr(L, f"dig_{fn}")(ctypes.byref(st), None) == -1, fn
-    assert L.dig_layernorm_bwd_blocks(ctypes.c_longlong(33)) == 2 and L.dig_colsum_chunks(ctypes.c_longlong(129)) == 2
+    assert L.dig_layernorm_bwd_blocks(ctypes.c_longlong(33)) == 5 and L.dig_colsum_chunks(ctypes.c_longlong(129)) == 2
 
 
 def test_adamw_rule_and_decay_filter():

@@ -1,0 +1,36 @@
+"""Every C-ABI launch of one training step (B images, 224x224) with its shape fields and HIP-event time, by entry point."""
+import sys, os, torch, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from dig_amd import _lib, synth, train
+from dig_amd.mctformer import create_model
+torch.set_grad_enabled(False)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+m = create_model("deit_small_MCTformerV2_DiG", pretrained=False, num_classes=20, lfca=False)
+synth.fill_state_dict(m, seed=0, skip_prefixes=("norm.",))
+m = m.cuda().eval()
+img = synth.synth_imagenet_images(B, 224, 224, seed=1).cuda()
+label = synth.synth_labels(B, 20, seed=2).cuda()
+opt = train.AdamW(m, lr=1e-5)
+for _ in range(2): train.update_cls_step(m, opt, img, label)
+torch.cuda.synchronize()
+log, pend = [], []
+KEYS = ("M", "N", "K", "batch", "sam", "sak", "sbk", "sbn", "rows", "D", "n")
+def trace(fn, kw, phase):
+    ev = torch.cuda.Event(enable_timing=True); ev.record()
+    if phase == 0: pend.append(ev); return
+    log.append((fn, tuple((k, kw[k]) for k in KEYS if k in kw), pend.pop(), ev))
+_lib.TRACE = trace
+train.update_cls_step(m, opt, img, label)
+torch.cuda.synchronize()
+_lib.TRACE = None
+agg = collections.defaultdict(lambda: [0, 0.0])
+for fn, key, a, b in log:
+    k = (fn, key if fn in ("gemm_f32", "gemm_nt") else ())
+    agg[k][0] += 1; agg[k][1] += a.elapsed_time(b) * 1e3
+tot = sum(v[1] for v in agg.values())
+for k, v in sorted(agg.items(), key=lambda x: -x[1][1])[:40]:
+    fl = ""
+    d = dict(k[1])
+    if "K" in d: fl = f"{2 * d['M'] * d['N'] * d['K'] * d.get('batch', 1) * v[0] / v[1] / 1e6:7.1f} TF"
+    print(f"{k[0]:16s} x{v[0]:4d} {v[1]:9.1f} us {100 * v[1] / tot:5.1f}% {fl}  {d}")
+print("total", tot)
