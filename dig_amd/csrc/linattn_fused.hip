@@ -13,6 +13,8 @@
 //                       registers, y = M_b qs again taking the accumulator as the B operand, + bias, RMSNorm over
 //                       channels, * g2, + x (residual), written back through the wave's own rows of the LDS tile.
 // Storage type T in {bf16, float}; all statistics fp32.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -779,6 +781,9 @@ template <typename T, int KS> int launch_out(const dig_la_out_args* a, hipStream
     // sub-tiles per wave: the blocks that stage 70-100 KB of weights (one per CU) get as many as still leave a block per CU
     int iters = (int)(((long long)tiles * a->B) / ((BF && KS >= 8) ? 256 : 2048));
     iters = iters < 1 ? 1 : (iters > 8 ? 8 : iters);
+#ifdef LA_LAB
+    if (const char* e = getenv("DIG_LAOUT_ITERS")) iters = atoi(e);
+#endif
     hipLaunchKernelGGL((la_out_kernel<T, KS, DT, NW, WQL, MBL>), dim3((unsigned)((tiles + iters - 1) / iters), a->B), dim3(NW * 64), lds, st, *a, iters);
     return 0;
 }

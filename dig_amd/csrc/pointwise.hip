@@ -8,6 +8,8 @@
 //   + SiLU(GroupNorm(h2)) read back from the LDS rows in the accumulator's own layout (4 consecutive channels = 8 bytes),
 //   result written in place over the h2 rows and copied out as 16-byte NHWC vectors.
 // bf16 storage only (the fp32 parity mode keeps the general GEMM).
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -221,8 +223,13 @@ template <int KS, int NT, bool FIN = false> int launch(const dig_pw_res_args* a,
     }
     const long long nsub = a->M / 32;
     const long long groups = (nsub + 3) / 4;  // 4 sub-tiles (one per wave) per block-iteration
-    int iters = (int)(groups / 1024);
+    // sub-tile groups per block: the N = 128 instantiation (one block per CU, 51 KB of weights to stage per block) wants two
+    // rounds of blocks, not four (measured at M = 524288: 135 -> 117 us; the N = 64 one is flat from 4 to 16 iterations)
+    int iters = (int)(groups / (NT > 2 ? 512 : 1024));
     iters = iters < 1 ? 1 : (iters > 16 ? 16 : iters);
+#ifdef PW_LAB
+    if (const char* e = getenv("DIG_PW_ITERS")) iters = atoi(e);
+#endif
     const long long grid = (groups + iters - 1) / iters;
     hipLaunchKernelGGL((pw_res_kernel<KS, NT, FIN>), dim3((unsigned)grid), dim3(256), lds, st, *a, iters);
     DIG_LAUNCH_CHECK("pw_res");
