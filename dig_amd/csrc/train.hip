@@ -239,17 +239,125 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* x, const flo
     }
 }
 
-// softmax backward on rows of n: ds = scale * p * (dp - sum_j p_j dp_j), in place over dp; one wave per row
-__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* p, float* dp, long long rows, int n, float scale) {
+// softmax backward on rows of n: ds = scale * p * (dp - sum_j p_j dp_j), in place over dp; one wave per row.  g (optional,
+// [B][N][n]): the gradient that reaches EVERY head's probabilities through the head-averaged roll-up (mctformer.py:302-315),
+// added to dp first; row = (b * heads + h) * N + i reads g row b * N + i.
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(dig_softmax_bwd_args a) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float* pr = p + (size_t)row * n;
-    float* dr = dp + (size_t)row * n;
+    if (row >= a.rows) return;
+    const int n = a.n;
+    const float* pr = a.p + (size_t)row * n;
+    float* dr = a.dp + (size_t)row * n;
+    const float* gr = nullptr;
+    if (a.g) {
+        const long long per_img = (long long)a.heads * a.N;
+        gr = a.g + (size_t)((row / per_img) * a.N + row % a.N) * n;
+    }
     float s = 0.f;
-    for (int j = lane; j < n; j += 64) s += pr[j] * dr[j];
+    for (int j = lane; j < n; j += 64) s += pr[j] * (gr ? dr[j] + gr[j] : dr[j]);
     s = wave_sum(s);
-    for (int j = lane; j < n; j += 64) dr[j] = scale * pr[j] * (dr[j] - s);
+    for (int j = lane; j < n; j += 64) dr[j] = a.scale * pr[j] * ((gr ? dr[j] + gr[j] : dr[j]) - s);
+}
+
+// out[b][i] (+)= scale * sum_h p[b][h][i]: the head mean / layer sum of the attention probabilities (mctformer.py:302-303,310,315)
+__global__ __launch_bounds__(256) void head_sum_kernel(dig_head_sum_args a) {
+    const long long total = (long long)a.B * a.n;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long b = i / a.n, r = i - b * a.n;
+        const float* p = a.p + (size_t)b * a.H * a.n + r;
+        float s = 0.f;
+        for (int h = 0; h < a.H; h++) s += p[(size_t)h * a.n];
+        s *= a.scale;
+        a.out[i] = a.accumulate ? a.out[i] + s : s;
+    }
+}
+
+// adjoint of  | (max_norm(a) * (a_times_label ? label : 1) - max_norm(b)) * label |  summed over the map, w.r.t. b (same map
+// size on both sides).  max_norm(x) = relu(relu(x) - min - 1e-5) / (max - min + 1e-5), min / max over the map of relu(x)
+// (model.py:572-578): the gradient also reaches the positions that ARE the maximum and the minimum, as autograd's does.
+// One block per (image, class); db is written in full.
+__global__ __launch_bounds__(256) void maxnorm_l1_bwd_kernel(dig_maxnorm_l1_bwd_args a) {
+    extern __shared__ float lsm[];
+    __shared__ float red[32];
+    __shared__ int redi[8];
+    const int P = a.P, bc = blockIdx.x, tid = threadIdx.x;
+    float* am = lsm;       // relu(a)
+    float* bm = am + P;    // relu(b)
+    float* gm = bm + P;    // d loss / d max_norm(b)
+    const float* ap = a.a + (size_t)bc * P;
+    const float* bp = a.b + (size_t)bc * P;
+    float amax = -INFINITY, amin = INFINITY, bmax = -INFINITY, bmin = INFINITY;
+    for (int i = tid; i < P; i += 256) {
+        const float av = fmaxf(ap[i], 0.f), bv = fmaxf(bp[i], 0.f);
+        am[i] = av;
+        bm[i] = bv;
+        amax = fmaxf(amax, av);
+        amin = fminf(amin, av);
+        bmax = fmaxf(bmax, bv);
+        bmin = fminf(bmin, bv);
+    }
+    amax = block_max(amax, red);
+    amin = -block_max(-amin, red);
+    bmax = block_max(bmax, red);
+    bmin = -block_max(-bmin, red);
+    // first position of the maximum / minimum (torch.max / torch.min over a dimension return one index each)
+    int imax = P, imin = P;
+    for (int i = tid; i < P; i += 256) {
+        if (bm[i] == bmax) imax = min(imax, i);
+        if (bm[i] == bmin) imin = min(imin, i);
+    }
+    auto block_min_i = [&](int v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+        __syncthreads();
+        if ((tid & 63) == 0) redi[tid >> 6] = v;
+        __syncthreads();
+        return min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+    };
+    imax = block_min_i(imax);
+    imin = block_min_i(imin);
+    const float lab = a.label[bc], la = a.a_times_label ? lab : 1.f;
+    const float aden = amax - amin + 1e-5f, den = bmax - bmin + 1e-5f;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = tid; i < P; i += 256) {
+        const float an = fmaxf(am[i] - amin - 1e-5f, 0.f) / aden;
+        const float u = bm[i] - bmin - 1e-5f;
+        const float bn = fmaxf(u, 0.f) / den;
+        const float d = (an * la - bn) * lab;
+        const float g = -(d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * lab * a.scale;
+        const float du = u > 0.f ? g / den : 0.f;
+        gm[i] = du;
+        s1 += g * fmaxf(u, 0.f);
+        s2 += du;
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    const float dden = -s1 / (den * den);
+    const float dmx = dden, dmn = -dden - s2;
+    float* db = a.db + (size_t)bc * P;
+    for (int i = tid; i < P; i += 256) {
+        float g = gm[i];
+        if (i == imax) g += dmx;
+        if (i == imin) g += dmn;
+        db[i] = bp[i] > 0.f ? g : 0.f;
+    }
+}
+
+// adjoint of the CAM aggregation's elementwise part (mctformer.py:306-312: cams = mtatt * relu(head)), and of cams = relu(head)
+// alone (mtatt == NULL: outputs['cams'], the CAM-consistency term): for dcams [B][C][P]
+//   G[b][c][C + j]  = inv_heads * dcams * relu(head)          (mtatt's share: class-token rows of the roll-up gradient; G optional)
+//   dhead[b][j][c] += dcams * (mtatt or 1) * [head > 0]       (NHWC, padded to Cp channels)
+__global__ __launch_bounds__(256) void cam_fuse_bwd_kernel(dig_cam_fuse_bwd_args a) {
+    const long long total = (long long)a.B * a.C * a.P;
+    const int N = a.C + a.P;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int j = (int)(i % a.P), c = (int)((i / a.P) % a.C), b = (int)(i / ((long long)a.P * a.C));
+        const float d = a.dcams[i];
+        const float hv = a.head[((size_t)b * a.P + j) * a.C + c];
+        if (a.G) a.G[((size_t)b * N + c) * N + a.C + j] = a.inv_heads * d * fmaxf(hv, 0.f);
+        if (hv > 0.f) a.dhead[((size_t)b * a.P + j) * a.Cp + c] += d * (a.mtatt ? a.mtatt[i] : 1.f);
+    }
 }
 
 // d/dx of scale * F.multilabel_soft_margin_loss(x, y): scale * (sigmoid(x) - y) / (B C)
@@ -387,7 +495,8 @@ extern "C" int dig_softmax_bwd(const dig_softmax_bwd_args* a, void* stream_) {
     DIG_CHECK(a && a->p && a->dp && a->rows > 0 && a->n > 0, DIG_EINVAL, "softmax_bwd: bad argument");
     const long long blocks = (a->rows + 3) / 4;
     DIG_CHECK(blocks < (1ll << 31), DIG_EINVAL, "softmax_bwd: too many rows");
-    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a->p, a->dp, a->rows, a->n, a->scale);
+    DIG_CHECK(!a->g || (a->heads > 0 && a->N > 0 && a->rows % ((long long)a->heads * a->N) == 0), DIG_EINVAL, "softmax_bwd: the roll-up gradient needs heads, N with rows = B * heads * N");
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, *a);
     DIG_LAUNCH_CHECK("softmax_bwd");
     return DIG_OK;
 }
@@ -416,5 +525,33 @@ extern "C" int dig_adamw(const dig_adamw_args* a, void* stream_) {
     const long long blocks = (a->n + 255) / 256;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, *a);
     DIG_LAUNCH_CHECK("adamw");
+    return DIG_OK;
+}
+
+extern "C" int dig_head_sum(const dig_head_sum_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->p && a->out && a->B > 0 && a->H > 0 && a->n > 0, DIG_EINVAL, "head_sum: bad argument");
+    const long long blocks = ((long long)a->B * a->n + 255) / 256;
+    hipLaunchKernelGGL(head_sum_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream, *a);
+    DIG_LAUNCH_CHECK("head_sum");
+    return DIG_OK;
+}
+
+extern "C" int dig_maxnorm_l1_bwd(const dig_maxnorm_l1_bwd_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->a && a->b && a->label && a->db, DIG_EINVAL, "maxnorm_l1_bwd: null pointer");
+    DIG_CHECK(a->B > 0 && a->C > 0 && a->P > 0 && (size_t)a->P * 12 <= 60 * 1024, DIG_EINVAL, "maxnorm_l1_bwd: bad shape B=%d C=%d P=%d (P <= 5120)", a->B, a->C, a->P);
+    hipLaunchKernelGGL(maxnorm_l1_bwd_kernel, dim3((unsigned)(a->B * a->C)), dim3(256), (size_t)a->P * 12, stream, *a);
+    DIG_LAUNCH_CHECK("maxnorm_l1_bwd");
+    return DIG_OK;
+}
+
+extern "C" int dig_cam_fuse_bwd(const dig_cam_fuse_bwd_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->dcams && a->head && a->dhead, DIG_EINVAL, "cam_fuse_bwd: null pointer");
+    DIG_CHECK(a->B > 0 && a->C > 0 && a->P > 0 && a->Cp >= a->C && (!a->G || a->inv_heads > 0.f), DIG_EINVAL, "cam_fuse_bwd: bad argument");
+    const long long blocks = ((long long)a->B * a->C * a->P + 255) / 256;
+    hipLaunchKernelGGL(cam_fuse_bwd_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream, *a);
+    DIG_LAUNCH_CHECK("cam_fuse_bwd");
     return DIG_OK;
 }

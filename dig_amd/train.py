@@ -11,8 +11,9 @@ forward is re-run with its intermediates kept (`forward_train`), and `backward_c
 adjoint kernels of csrc/train.hip (dig_gemm_f32 with transposed operands as stride pairs, dig_layernorm_bwd, dig_gelu_bwd,
 dig_softmax_bwd, dig_head_pool_bwd, dig_msm_grad, dig_colsum); `AdamW` is torch.optim.AdamW's update with timm's no-decay
 filter.  fp32, eval-mode semantics (no DropPath / dropout: the product's MCTformer refuses drop rates), no atomics - a step is
-bitwise reproducible.  Built for the loss terms that need one plain MCTformer pass (loss_cls, loss_cls_diff); the LFCA / KD,
-CAM-consistency and rcams-consistency terms have forward kernels only (dig_amd/losses.py).
+bitwise reproducible.  Built for every loss term that does not differentiate through the LFCA branch: loss_cls, loss_cls_diff,
+loss_cam_consistency (cam_diff enters detached) and loss_rcams_consistency (through the attention roll-up of all twelve layers);
+loss_pred_diff (the LFCA / distillation term) has forward kernels only (dig_amd/losses.py).
 torch allocates, copies and reshapes; every arithmetic operation is a C-ABI launch.  There is no CPU fallback.
 """
 import math
@@ -95,9 +96,10 @@ def layernorm_bwd(x, gamma, dy, add=None, eps=1e-6):
     return dx, gb[:D], gb[D:]
 
 
-def forward_train(m, img):
+def forward_train(m, img, want_cam=False):
     """MCTformerV2_DiG.forward without the LFCA branch (mctformer.py:227-263,293-300,318), keeping what the backward needs.
-    -> (outs {cls, pcls}, ctx)."""
+    -> (outs {cls, pcls}, ctx); want_cam adds the CAM outputs the consistency terms use (cams = relu(head), mtatt, fcams, rcams:
+    mctformer.py:302-321,334-338) from the head-averaged, layer-summed roll-up of the kept attention probabilities."""
     if not img.is_cuda:
         raise RuntimeError("dig_amd.train runs on the HIP device only (no CPU fallback)")
     P = _pack(m)
@@ -119,6 +121,7 @@ def forward_train(m, img):
     ops.gemm_nt(rows, P["pe_w"], (x, C * D), Pn, D, 3 * ps * ps, dtype=F32, bias=P["pe_b"], res=(pos, C * D), ldr=D,
                 batch=B, sa=(Pn * 3 * ps * ps, 0), sc=(N * D, 0), sr=(0, 0))
     saved = []
+    acc = torch.zeros(B, N, N, dtype=F32, device=dev) if want_cam else None
     for bp in P["blocks"]:
         x0 = x
         y1 = _layernorm(x0, bp["n1"])
@@ -127,6 +130,8 @@ def forward_train(m, img):
         gemm_f32(qkv, (qkv, D), S, N, N, dh, sam=3 * D, sak=1, sbk=1, sbn=3 * D, alpha=dh ** -0.5, batch=B * heads, z_inner=heads,
                  sa=(N * 3 * D, dh), sb=(N * 3 * D, dh), sc=(heads * N * N, N * N))
         Pm = ops.row_softmax(S, F32)
+        if want_cam:
+            call("head_sum", p=Pm, out=acc, n=N * N, B=B, H=heads, accumulate=1, scale=1.0 / heads)
         o = torch.empty(B, N, D, dtype=F32, device=dev)
         gemm_f32(Pm, (qkv, 2 * D), o, N, dh, N, sam=N, sak=1, sbk=3 * D, sbn=1, ldc=D, batch=B * heads, z_inner=heads,
                  sa=(heads * N * N, N * N), sb=(N * 3 * D, dh), sc=(N * D, dh))
@@ -145,13 +150,24 @@ def forward_train(m, img):
     cls = torch.empty(B, C, dtype=F32, device=dev)
     call("row_mean", x0=x, x1=None, out=cls, bstride0=N * D, bstride1=0, B=B, C=C, D=D)
     ctx = dict(rows=rows, saved=saved, x=x, head=head, dims=(B, C, D, heads, dh, hp, wp, Pn, N, ps))
-    return {"cls": cls, "pcls": pcls}, ctx
+    outs = {"cls": cls, "pcls": pcls}
+    if want_cam:
+        relu_head = torch.empty(B, C, hp, wp, dtype=F32, device=dev)
+        call("head_pool", **{"in": head}, relu_nchw=relu_head, pooled=None, B=B, P=Pn, C=C)
+        mtatt, fcams, rcams = (torch.empty(B, C, hp, wp, dtype=F32, device=dev) for _ in range(3))
+        call("cam_fuse", acc_all=acc, acc_cls=acc[:, :C].contiguous(), head=head, mtatt=mtatt, cams=fcams, rcams=rcams, B=B, C=C, P=Pn)
+        outs.update(cams=relu_head, mtatt=mtatt, fcams=fcams, rcams=rcams)
+        ctx.update(acc=acc, mtatt=mtatt, fcams=fcams)
+    return outs, ctx
 
 
-def backward_cls(m, outs, ctx, label, weight=1.0, grads=None):
+def backward_cls(m, outs, ctx, label, weight=1.0, grads=None, d_cams=None, d_rcams=None):
     """d/dparams of  weight * (F.multilabel_soft_margin_loss(cls, label) + F.multilabel_soft_margin_loss(pcls, label))
-    (model.py:337-340 with weight = W[0]; :406-409 with W[3] on the img_diff pass).  -> {named_parameters() key: gradient};
-    with `grads` given (a second pass of the same step) the new gradients are accumulated into it, as autograd's .grad does."""
+    (model.py:337-340 with weight = W[0]; :406-409 with W[3] on the img_diff pass), plus - for a forward_train(want_cam=True)
+    pass - the gradients that arrive at its CAM outputs: d_cams [B,C,hp,wp] w.r.t. outs['cams'] = relu(head) (the
+    CAM-consistency term) and d_rcams w.r.t. outs['rcams'] (the rcams-consistency term, which reaches the attention
+    probabilities of every layer through the roll-up).  -> {named_parameters() key: gradient}; with `grads` given (a second
+    pass of the same step) the new gradients are accumulated into it, as autograd's .grad does."""
     P = _pack(m)
     B, C, D, heads, dh, hp, wp, Pn, N, ps = ctx["dims"]
     dev = ctx["x"].device
@@ -167,6 +183,19 @@ def backward_cls(m, outs, ctx, label, weight=1.0, grads=None):
     Cp = (C + 7) // 8 * 8
     dhead = torch.empty(B, hp, wp, Cp, dtype=F32, device=dev)
     call("head_pool_bwd", head=ctx["head"], dpooled=dpcls, dhead=dhead, B=B, P=Pn, C=C, Cp=Cp)
+    # ---- CAM outputs (mctformer.py:302-321): cams = relu(head); fcams = mtatt * relu(head); rcams = patch_attn @ fcams
+    G = None
+    if d_cams is not None:
+        call("cam_fuse_bwd", dcams=d_cams.contiguous(), mtatt=None, head=ctx["head"], G=None, dhead=dhead, B=B, C=C, P=Pn, Cp=Cp, inv_heads=0.0)
+    if d_rcams is not None:
+        acc, drc = ctx["acc"], d_rcams.contiguous()
+        G = torch.zeros(B, N, N, dtype=F32, device=dev)  # gradient of the roll-up (head mean, layer sum): added to every layer's dP
+        dfc = torch.empty(B, C, Pn, dtype=F32, device=dev)
+        # dfcams[c][j] = sum_i patch_attn[i][j] drc[c][i];  dpatch_attn[i][j] = sum_c drc[c][i] fcams[c][j]  (/ heads into G)
+        gemm_f32(drc, (acc, C * N + C), dfc, C, Pn, Pn, sam=Pn, sak=1, sbk=N, sbn=1, batch=B, sa=(C * Pn, 0), sb=(N * N, 0), sc=(C * Pn, 0))
+        gemm_f32(drc, ctx["fcams"], (G, C * N + C), Pn, Pn, C, sam=1, sak=Pn, sbk=Pn, sbn=1, ldc=N, alpha=1.0 / heads, batch=B,
+                 sa=(C * Pn, 0), sb=(C * Pn, 0), sc=(N * N, 0))
+        call("cam_fuse_bwd", dcams=dfc, mtatt=ctx["mtatt"], head=ctx["head"], G=G, dhead=dhead, B=B, C=C, P=Pn, Cp=Cp, inv_heads=1.0 / heads)
     new["head.bias"] = colsum(dhead, B * Pn, Cp)[:C].clone()
     # weight gradient on the zero-padded domain: a tap is then a constant element offset, dW_tap = dYpad^T Xpad[+off]
     xfin = ctx["x"]
@@ -214,7 +243,7 @@ def backward_cls(m, outs, ctx, label, weight=1.0, grads=None):
         gemm_f32(Pm, do, (dqkv, 2 * D), N, dh, N, sam=1, sak=N, sbk=D, sbn=1, ldc=3 * D, sa=sP, sb=sO, sc=sq, **bh)            # dV = P^T dO
         dP = torch.empty(B, heads, N, N, dtype=F32, device=dev)
         gemm_f32(do, (qkv, 2 * D), dP, N, N, dh, sam=D, sak=1, sbk=1, sbn=3 * D, sa=sO, sb=sq, sc=sP, **bh)                    # dP = dO V^T
-        call("softmax_bwd", p=Pm, dp=dP, rows=B * heads * N, n=N, scale=dh ** -0.5)                                               # dS (of q k^T)
+        call("softmax_bwd", p=Pm, dp=dP, g=G, rows=B * heads * N, n=N, heads=heads, N=N, scale=dh ** -0.5)                                               # dS (of q k^T)
         gemm_f32(dP, (qkv, D), dqkv, N, dh, N, sam=N, sak=1, sbk=3 * D, sbn=1, ldc=3 * D, sa=sP, sb=sq, sc=sq, **bh)            # dQ = dS K
         gemm_f32(dP, qkv, (dqkv, D), N, dh, N, sam=1, sak=N, sbk=3 * D, sbn=1, ldc=3 * D, sa=sP, sb=sq, sc=sq, **bh)            # dK = dS^T Q
         dy1, dw, db = linear_bwd(sv["y1"].reshape(M, D), bp["qkv"][0], dqkv.reshape(M, 3 * D), M)
@@ -283,22 +312,65 @@ class AdamW:
             self.model._packed_lfca = None
 
 
-def update_cls_step(m, opt, img, label, W0=1.0, img_diff=None, W3=1.0):
-    """One optimiser step on loss_cls (+ loss_cls_diff when img_diff is given): zero_grad, forward, backward, step
-    (model.py:319-341,396-410,424-425).  -> (loss_trm as a device scalar, grads)."""
-    from .losses import _msm
-    outs, ctx = forward_train(m, img)
+def maxnorm_l1_bwd(a, b, label, scale, a_times_label):
+    """scale * d/db sum | (max_norm(a) [* label] - max_norm(b)) * label |  (dig_maxnorm_l1_bwd; a, b [B,C,h,w] of one size)"""
+    if a.shape != b.shape:
+        raise NotImplementedError("dig_amd.train: the consistency terms are differentiated for equal map sizes only "
+                                  f"(got {tuple(a.shape)} vs {tuple(b.shape)}: the bilinear resize has no adjoint kernel yet)")
+    B, C, h, w = b.shape
+    db = torch.empty(B, C, h, w, dtype=F32, device=b.device)
+    call("maxnorm_l1_bwd", a=a.contiguous().float(), b=b.contiguous(), label=label, db=db, B=B, C=C, P=h * w,
+         a_times_label=int(a_times_label), scale=float(scale))
+    return db
+
+
+def update_step(m, opt, img, label, W=(1.0, 0.0, 1.0, 1.0, 10.0), img_diff=None, cam_diff=None, epo=10):
+    """One optimiser step of model_WSSS.update's MCTformer part (model.py:319-341,367-425) for the terms that do not
+    differentiate through the LFCA branch:
+        W[0] loss_cls + W[2] loss_cam_consistency (cam_diff = the LFCA output of this batch, a constant of the loss; epo > 9)
+        + W[3] loss_cls_diff + W[4] loss_rcams_consistency (both on img_diff, the t = 100 reconstruction; epo > 9)
+    W[1] (loss_pred_diff: soft-margin + distillation on the LFCA outputs) needs the LFCA backward, which is not built: a
+    non-zero W[1] raises.  zero_grad -> two forward passes with kept activations -> backward -> AdamW.
+    -> (loss_trm as a device scalar, grads)."""
+    from .losses import LFCA_EPOCH, _maxnorm_l1, _msm
+    if W[1] > 0:
+        raise NotImplementedError("dig_amd.train.update_step: W[1] > 0 (loss_pred_diff) needs the backward of the LFCA branch")
     dev = img.device
     lab = label.to(dev).float().contiguous()
+    B, C = lab.shape
+    late = epo > LFCA_EPOCH
+    use_cam = W[2] > 0 and late and cam_diff is not None
+    use_rc = W[4] > 0 and late and img_diff is not None
+    outs, ctx = forward_train(m, img, want_cam=use_cam or use_rc)
     loss = torch.zeros(1, dtype=F32, device=dev)
-    _msm(outs["cls"], lab, loss, W0, False)
-    _msm(outs["pcls"], lab, loss, W0, True)
-    grads = backward_cls(m, outs, ctx, lab, W0)
+    _msm(outs["cls"], lab, loss, W[0], False)
+    _msm(outs["pcls"], lab, loss, W[0], True)
+    d_cams = None
+    if use_cam:
+        hw = outs["cams"].shape[2] * outs["cams"].shape[3]
+        term = torch.zeros(1, dtype=F32, device=dev)
+        _maxnorm_l1(cam_diff, outs["cams"], lab, term, W[2], True)
+        _add_into(loss, term)
+        d_cams = maxnorm_l1_bwd(cam_diff, outs["cams"], lab, W[2] / (B * C * hw), True)
+    rc1 = outs["rcams"] if use_rc else None
+    grads = backward_cls(m, outs, ctx, lab, W[0], d_cams=d_cams)
     del ctx
-    if img_diff is not None:
-        outs2, ctx2 = forward_train(m, img_diff)
-        _msm(outs2["cls"], lab, loss, W3, True)
-        _msm(outs2["pcls"], lab, loss, W3, True)
-        grads = backward_cls(m, outs2, ctx2, lab, W3, grads=grads)
+    if img_diff is not None and (W[3] > 0 or use_rc):
+        outs2, ctx2 = forward_train(m, img_diff, want_cam=use_rc)
+        _msm(outs2["cls"], lab, loss, W[3], True)
+        _msm(outs2["pcls"], lab, loss, W[3], True)
+        d_rc = None
+        if use_rc:
+            hw = rc1.shape[2] * rc1.shape[3]
+            term = torch.zeros(1, dtype=F32, device=dev)
+            _maxnorm_l1(rc1, outs2["rcams"], lab, term, W[4], False)
+            _add_into(loss, term)
+            d_rc = maxnorm_l1_bwd(rc1, outs2["rcams"], lab, W[4] / (B * C * hw), False)
+        grads = backward_cls(m, outs2, ctx2, lab, W[3], grads=grads, d_rcams=d_rc)
     opt.step(grads)
     return loss, grads
+
+
+def update_cls_step(m, opt, img, label, W0=1.0, img_diff=None, W3=1.0):
+    """update_step restricted to the classification terms (loss_cls, and loss_cls_diff when img_diff is given)."""
+    return update_step(m, opt, img, label, W=(W0, 0.0, 0.0, W3 if img_diff is not None else 0.0, 0.0), img_diff=img_diff, epo=0)

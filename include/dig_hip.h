@@ -670,8 +670,10 @@ int dig_gelu_bwd(const dig_gelu_bwd_args* a, void* stream);
 typedef struct {
     const float* p;
     float* dp;
+    const float* g; /* NULL, or [B][N][n]: added to every head's dp first - the gradient of the head-averaged, layer-summed roll-up
+                     * (mctformer.py:302-315) that the rcams-consistency term sends into each layer's probabilities; rows = B*heads*N */
     long long rows;
-    int n;
+    int n, heads, N;
     float scale;
 } dig_softmax_bwd_args;
 int dig_softmax_bwd(const dig_softmax_bwd_args* a, void* stream);
@@ -708,6 +710,44 @@ typedef struct {
     float lr, wd, beta1, beta2, eps, step_size, sqrt_bc2;
 } dig_adamw_args;
 int dig_adamw(const dig_adamw_args* a, void* stream);
+
+/* out[b][i] (+)= scale * sum_h p[b][h][i], p [B][H][n]: the roll-up of a layer's attention probabilities (torch.mean over heads,
+ * sum over layers: mctformer.py:302-303,310,315) that the training forward keeps for the CAM outputs */
+typedef struct {
+    const float* p;
+    float* out;
+    long long n;
+    int B, H, accumulate;
+    float scale;
+} dig_head_sum_args;
+int dig_head_sum(const dig_head_sum_args* a, void* stream);
+
+/* db = scale * d/db sum_hw | (max_norm(a) * (a_times_label ? label : 1) - max_norm(b)) * label |, a, b, db [B][C][P] (equal map
+ * sizes), max_norm = model.py:572-578 incl. the paths through the map's maximum and minimum: the adjoint of dig_maxnorm_l1
+ * (loss_cam_consistency model.py:388-390 w.r.t. cams, loss_rcams_consistency :415-417 w.r.t. the img_diff pass's rcams) */
+typedef struct {
+    const float* a;
+    const float* b;
+    const float* label;
+    float* db;
+    int B, C, P, a_times_label;
+    float scale;
+} dig_maxnorm_l1_bwd_args;
+int dig_maxnorm_l1_bwd(const dig_maxnorm_l1_bwd_args* a, void* stream);
+
+/* elementwise adjoint of cams = mtatt * relu(head) (mctformer.py:306-312; mtatt NULL: cams = relu(head), :334) for dcams [B][C][P]:
+ *   G[b][c][C+j] = inv_heads * dcams * relu(head)   (G NULL or [B][C+P][C+P]: the roll-up gradient, class-token rows)
+ *   dhead[b][j][c] += dcams * (mtatt or 1) * [head > 0]   (head [B][P][C], dhead [B][P][Cp]) */
+typedef struct {
+    const float* dcams;
+    const float* mtatt;
+    const float* head;
+    float* G;
+    float* dhead;
+    int B, C, P, Cp;
+    float inv_heads;
+} dig_cam_fuse_bwd_args;
+int dig_cam_fuse_bwd(const dig_cam_fuse_bwd_args* a, void* stream);
 
 #ifdef __cplusplus
 }

@@ -492,6 +492,34 @@ def mct_cls_loss_grads(sd, img, label, w0=1.0):
     return float(loss.detach()), {k: g for k, g in zip(names, grads) if g is not None}
 
 
+def mct_consistency_loss_grads(sd, img, img_diff, cam_diff, label, W=(1.0, 0.0, 1.0, 1.0, 10.0)):
+    """loss_trm.backward() (model.py:424) for every term that does not differentiate through the LFCA branch:
+      W[0] loss_cls (:337-340) + W[2] loss_cam_consistency (:368-390, cam_diff enters detached) + W[3] loss_cls_diff (:406-409)
+      + W[4] loss_rcams_consistency (:414-418, the first pass's rcams detached),
+    by autograd over this file's forward restatement of the two MCTformer passes (eval mode).  cam_diff: the LFCA output of the
+    first pass (any tensor of its shape: it is a constant of the loss).  W[1] (loss_pred_diff) must be 0 here.
+    -> (loss_trm, {state_dict key: gradient})."""
+    assert W[1] == 0
+    B, C = label.shape
+    lab4 = label.view(B, C, 1, 1)
+    msm = F.multilabel_soft_margin_loss
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
+    with torch.enable_grad():
+        o1 = mctformer_outputs(leaves, img)
+        o2 = mctformer_outputs(leaves, img_diff)
+        loss = W[0] * (msm(o1["cls"], label) + msm(o1["pcls"], label))
+        if W[2] > 0:
+            _cams = max_norm(F.interpolate(o1["cams"], size=cam_diff.shape[2:], mode="bilinear", align_corners=False))
+            _cam_diff = max_norm(cam_diff) * lab4
+            loss = loss + W[2] * ((_cam_diff.detach() - _cams) * lab4).abs().mean()
+        loss = loss + W[3] * (msm(o2["cls"], label) + msm(o2["pcls"], label))
+        if W[4] > 0:
+            loss = loss + W[4] * ((max_norm(o1["rcams"]).detach() - max_norm(o2["rcams"])) * lab4).abs().mean()
+        names = [k for k in leaves]
+        grads = torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)
+    return float(loss.detach()), {k: g for k, g in zip(names, grads) if g is not None}
+
+
 def adamw_no_decay(name, p):
     """timm.optim.create_optimizer's weight-decay filter (optim_factory.add_weight_decay, timm 0.3.x - the version the DiG
     repo pins; timm itself is not importable here, so this is a restatement of its published rule and PARITY UNPINNED on

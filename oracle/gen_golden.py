@@ -337,6 +337,51 @@ def case_grads(mct, name, C, H, W, B, w0=1.0, lr=5e-4 * 32 / 512.0, wd=0.05):
     save(name, **arrays)
 
 
+def case_grads_consistency(mct, name, C, H, W, B, hd, wd, Wt=(1.0, 0.0, 1.0, 1.0, 10.0)):
+    """(f)-4: loss_trm.backward() of the REFERENCE for the four terms that do not differentiate through the LFCA branch
+    (model.py:337-340, 368-390, 396-418 with W[1] = 0, epo past the LFCA gate): two reference MCTformer passes in eval mode
+    (the first with the LFCA branch, which supplies cam_diff), the reference's own loss expressions, .grad of the ViT
+    parameters as norm / sum / 256 sampled entries each.  cam_diff is stored (fp16) as the fixture's input."""
+    m = mct.deit_small_MCTformerV2_DiG(num_classes=C).eval()
+    synth.fill_state_dict(m, seed=0, skip_prefixes=("norm.",))
+    sd = {k: v.clone() for k, v in m.state_dict().items() if not k.startswith(("LFCA", "diff_head_p"))}
+    img = synth.synth_imagenet_images(B, H, W, seed=6200)
+    img_diff = synth.synth_imagenet_images(B, H, W, seed=6201)
+    label = synth.synth_labels(B, C, seed=14)
+    feat = [synth.normal("feat_diff", (B, 1024, hd, wd), seed=27 + j) * 1.5 for j in range(5)]
+    Fn = torch.nn.functional
+    lab4 = label.view(B, C, 1, 1)
+    mn = m.max_norm
+    with torch.enable_grad():
+        for p in m.parameters():
+            p.requires_grad_(True)
+        o1 = m(img, feat_diff=feat)
+        o2 = m(img_diff)
+        cam_diff = o1["cam_diff"].detach().half().float()  # the fixture keeps fp16: make that the constant of the loss
+        msm = Fn.multilabel_soft_margin_loss
+        loss = Wt[0] * (msm(o1["cls"], label) + msm(o1["pcls"], label))
+        _cams = mn(Fn.interpolate(o1["cams"], size=cam_diff.size()[2:], mode="bilinear", align_corners=False))
+        _cam_diff = mn(cam_diff) * lab4
+        loss = loss + Wt[2] * ((_cam_diff.detach() - _cams) * lab4).abs().mean()
+        loss = loss + Wt[3] * (msm(o2["cls"], label) + msm(o2["pcls"], label))
+        loss = loss + Wt[4] * ((mn(o1["rcams"]).detach() - mn(o2["rcams"])) * lab4).abs().mean()
+        loss.backward()
+    ref = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None and not k.startswith(("LFCA", "diff_head_p"))}
+    lo, og = O.mct_consistency_loss_grads(sd, img, img_diff, cam_diff, label, Wt)
+    assert set(og) == set(ref), sorted(set(og) ^ set(ref))
+    rel = max(float((og[k] - ref[k]).norm() / (ref[k].norm() + 1e-30)) for k in ref)
+    arrays = {"label": label, "loss": np.float64(float(loss)), "W": np.array(Wt, np.float64), "cam_diff": cam_diff.half()}
+    names = sorted(ref)
+    arrays["names"] = np.array(names)
+    for i, k in enumerate(names):
+        idx = synth.sample_index(k, ref[k].numel())
+        arrays[f"g{i}_norm"] = np.float64(float(ref[k].double().norm()))
+        arrays[f"g{i}_sum"] = np.float64(float(ref[k].double().sum()))
+        arrays[f"g{i}_s"] = ref[k].flatten()[idx]
+    record(name, loss=abs(lo - float(loss)), grad_rel=rel)
+    save(name, **arrays)
+
+
 def synth_eval_set(C=20, seed=5):
     """Small synthetic CAM dicts + ground-truth maps (with 255 boundary pixels) for the evaluation cases."""
     rng = np.random.RandomState(seed)
@@ -470,6 +515,7 @@ def main():
         return
     if sys.argv[1:] == ["grads"]:  # (f)-4: the reference's own .grad tensors (sampled) + one AdamW step
         case_grads(mct, "grads224_c20", 20, 224, 224, 2)
+        case_grads_consistency(mct, "grads_consistency224_c20", 20, 224, 224, 2, 14, 14)
         _merge_manifest()
         return
     if sys.argv[1:] == ["eval"]:
@@ -489,6 +535,7 @@ def main():
     case_cam(mct, "cam368x496_c20", 20, 368, 496, 1)
     case_envelope_full(ddp, "unet256_t100_img0", 256, 256, 0)
     case_grads(mct, "grads224_c20", 20, 224, 224, 2)
+    case_grads_consistency(mct, "grads_consistency224_c20", 20, 224, 224, 2, 14, 14)
     case_lfca(mct, "lfca224_c20", 20, 224, 224, 14, 14)
     case_lfca(mct, "lfca224_c20_maps16", 20, 224, 224, 16, 16)  # guidance maps from a 256x256 diffusion input: bilinear 14 -> 16
     case_eval(ref_import.load_evaluation())

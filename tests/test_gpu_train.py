@@ -209,3 +209,87 @@ def test_training_step_is_bitwise_reproducible_and_accumulates():
         acc = train.backward_cls(m, o, ctx, label.to(DEV), 0.5, grads={k: v.clone() for k, v in g1.items()})
     for k in g1:
         assert float((acc[k] - 1.5 * g1[k]).abs().max()) <= 1e-5 * float(g1[k].abs().max()) + 1e-9, k
+
+
+def test_maxnorm_l1_and_rollup_adjoints():
+    """dig_maxnorm_l1_bwd against autograd of the reference's expression (model.py:388-390,415-417 with max_norm :572-578,
+    incl. the gradient paths through the map's maximum and minimum), dig_softmax_bwd with the roll-up gradient, dig_head_sum."""
+    B, C, h, w = 3, 20, 14, 14
+    a = rnd(B, C, h, w, seed=21)
+    b = rnd(B, C, h, w, seed=22).requires_grad_(True)
+    label = (rnd(B, C, seed=23) > 0).float()
+    lab4 = label.view(B, C, 1, 1)
+
+    def mn(x):
+        x = torch.relu(x)
+        mx = x.flatten(2).max(-1)[0].view(B, C, 1, 1)
+        mi = x.flatten(2).min(-1)[0].view(B, C, 1, 1)
+        return torch.relu(x - mi - 1e-5) / (mx - mi + 1e-5)
+    for atl in (False, True):
+        b.grad = None
+        t = mn(a) * lab4 if atl else mn(a)
+        (2.5 * ((t.detach() - mn(b)) * lab4).abs().mean()).backward()
+        with torch.no_grad():
+            db = train.maxnorm_l1_bwd(a, b.detach(), label, 2.5 / (B * C * h * w), atl)
+        assert float((db - b.grad).abs().max()) <= 1e-6 * float(b.grad.abs().max()) + 1e-10, atl
+    # all-positive maps: the minimum is a real position and carries gradient too
+    b2 = (rnd(B, C, h, w, seed=24).abs() + 0.1).requires_grad_(True)
+    ((mn(a).detach() - mn(b2)) * lab4).abs().mean().backward()
+    with torch.no_grad():
+        db = train.maxnorm_l1_bwd(a, b2.detach(), label, 1.0 / (B * C * h * w), False)
+    assert float((db - b2.grad).abs().max()) <= 1e-6 * float(b2.grad.abs().max()) + 1e-10
+    # softmax adjoint with a gradient shared by the heads, and the head-mean roll-up itself
+    Bn, H, N = 2, 3, 37
+    sl = rnd(Bn, H, N, N, seed=25, scale=2.0).requires_grad_(True)
+    dp, g = rnd(Bn, H, N, N, seed=26), rnd(Bn, N, N, seed=27)
+    pm = (sl * 0.125).softmax(-1)
+    ((pm * dp).sum() + (pm.mean(1) * g * H).sum()).backward()
+    with torch.no_grad():
+        d = dp.clone()
+        call("softmax_bwd", p=pm.detach(), dp=d, g=g, rows=Bn * H * N, n=N, heads=H, N=N, scale=0.125)
+        assert float((d - sl.grad).abs().max()) <= 2e-6
+        acc = torch.ones(Bn, N, N, device=DEV)
+        call("head_sum", p=pm.detach(), out=acc, n=N * N, B=Bn, H=H, accumulate=1, scale=1.0 / H)
+        assert float((acc - 1.0 - pm.detach().mean(1)).abs().max()) <= 1e-6
+
+
+def test_consistency_terms_backward_vs_reference(golden):
+    """loss_cls + loss_cam_consistency + loss_cls_diff + loss_rcams_consistency (W = 1, 0, 1, 1, 10; epo past the LFCA gate):
+    forward value and every parameter gradient against tests/golden/grads_consistency224_c20.npz - the REFERENCE's own
+    loss.backward() over its two MCTformer passes (oracle/gen_golden.py grads) - and tensor by tensor against autograd over the
+    CPU oracle.  The rcams term reaches the attention probabilities of all twelve layers through the roll-up."""
+    fx = golden("grads_consistency224_c20")
+    W = tuple(float(v) for v in fx["W"])
+    m = make_mct(20)
+    img = synth.synth_imagenet_images(2, 224, 224, seed=6200).to(DEV)
+    img_diff = synth.synth_imagenet_images(2, 224, 224, seed=6201).to(DEV)
+    label = synth.synth_labels(2, 20, seed=14)
+    assert np.array_equal(label.numpy(), fx["label"])
+    cam_diff = T(fx["cam_diff"]).float().to(DEV)
+    before = {k: p.detach().clone() for k, p in m.named_parameters()}
+    opt = train.AdamW(m, lr=0.0, weight_decay=0.0)  # lr 0: the step leaves the parameters alone, the gradients are what is checked
+    with torch.no_grad():
+        loss, g = train.update_step(m, opt, img, label.to(DEV), W=W, img_diff=img_diff, cam_diff=cam_diff, epo=10)
+    assert all(torch.equal(before[k], p.detach()) for k, p in m.named_parameters())
+    assert abs(float(loss) - float(fx["loss"])) <= 1e-5 * abs(float(fx["loss"])), (float(loss), float(fx["loss"]))
+    names = [str(n) for n in fx["names"]]
+    assert set(names) == set(g), sorted(set(names) ^ set(g))
+    params = dict(m.named_parameters())
+    worst_rel, worst_samp = 0.0, 0.0
+    for i, k in enumerate(names):
+        gk = g[k].reshape(params[k].shape).float().cpu()
+        idx = synth.sample_index(k, gk.numel())
+        rs, rn = T(fx[f"g{i}_s"]), float(fx[f"g{i}_norm"])
+        samp = float((gk.flatten()[idx] - rs).abs().max())
+        dn = abs(float(gk.double().norm()) - rn) / (rn + 1e-30)
+        worst_rel, worst_samp = max(worst_rel, dn), max(worst_samp, samp / (float(rs.abs().max()) + 1e-12))
+        assert dn <= 1e-4, (k, dn)
+        assert samp <= 1e-4 * float(rs.abs().max()) + 1e-8, (k, samp)
+    print("consistency terms vs reference .grad: worst relative norm error", worst_rel, "worst sampled-entry error / max", worst_samp)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    lo, og = O.mct_consistency_loss_grads(sd, img.cpu(), img_diff.cpu(), cam_diff.cpu(), label, W)
+    worst = max(float((g[k].reshape(og[k].shape).cpu() - og[k]).norm() / (og[k].norm() + 1e-30)) for k in names)
+    print("consistency terms vs oracle autograd: worst relative L2 error:", worst)
+    assert worst <= 1e-4
+    with pytest.raises(NotImplementedError):
+        train.update_step(m, opt, img, label.to(DEV), W=(1.0, 1.0, 1.0, 1.0, 10.0), img_diff=img_diff, cam_diff=cam_diff)

@@ -45,7 +45,8 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert L.dig_gemm_nt(ctypes.byref(a), None) == -1 and b"null pointer" in L.dig_last_error()
     c = _lib.STRUCTS["dig_conv3x3_args"]()
     assert L.dig_conv3x3(ctypes.byref(c), None) == -1
-    for fn in ("gemm_f32", "layernorm_bwd", "colsum", "gelu_bwd", "softmax_bwd", "msm_grad", "head_pool_bwd", "adamw"):
+    for fn in ("gemm_f32", "layernorm_bwd", "colsum", "gelu_bwd", "softmax_bwd", "msm_grad", "head_pool_bwd", "adamw", "head_sum", "maxnorm_l1_bwd",
+               "cam_fuse_bwd"):
         st = _lib.STRUCTS[f"dig_{fn}_args"]()
         assert getattr(L, f"dig_{fn}")(ctypes.byref(st), None) == -1, fn
     assert L.dig_layernorm_bwd_blocks(ctypes.c_longlong(33)) == 5 and L.dig_colsum_chunks(ctypes.c_longlong(129)) == 2

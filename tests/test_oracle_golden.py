@@ -183,6 +183,28 @@ def test_backward_and_adamw_vs_reference_grads(golden):
             assert float((p.flatten()[idx] - T(g[f"p{i}_s"])).abs()[solid].max()) <= 0.01 * lr, k
 
 
+def test_consistency_terms_backward_vs_reference_grads(golden):
+    """loss_cls + loss_cam_consistency + loss_cls_diff + loss_rcams_consistency - autograd over the oracle's two
+    MCTformer passes against the reference's own .grad tensors (sampled) and loss value."""
+    g = golden("grads_consistency224_c20")
+    m = create_model("deit_small_MCTformerV2_DiG", pretrained=False, num_classes=20, lfca=False)
+    synth.fill_state_dict(m, seed=0, skip_prefixes=("norm.",))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    img = synth.synth_imagenet_images(2, 224, 224, seed=6200)
+    img_diff = synth.synth_imagenet_images(2, 224, 224, seed=6201)
+    label = synth.synth_labels(2, 20, seed=14)
+    assert np.array_equal(label.numpy(), g["label"])
+    loss, og = O.mct_consistency_loss_grads(sd, img, img_diff, T(g["cam_diff"]).float(), label, tuple(float(v) for v in g["W"]))
+    assert abs(loss - float(g["loss"])) <= 1e-6
+    names = [str(n) for n in g["names"]]
+    assert set(names) == set(og)
+    for i, k in enumerate(names):
+        idx = synth.sample_index(k, og[k].numel())
+        rs = T(g[f"g{i}_s"])
+        assert float((og[k].flatten()[idx] - rs).abs().max()) <= 1e-5 * float(rs.abs().max()) + 1e-9, k
+        assert abs(float(og[k].double().norm()) - float(g[f"g{i}_norm"])) <= 1e-5 * float(g[f"g{i}_norm"]) + 1e-12, k
+
+
 def _eval_set(g):
     dicts, gts = [], []
     i = 0
