@@ -436,6 +436,95 @@ __global__ __launch_bounds__(256) void adamw_kernel(dig_adamw_args a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// adjoints used by the LFCA branch (mctformer.py:56-166; resnet101.py:31-38,195-222)
+// GroupNorm(1, C) backward on NHWC x [B][HW][C]: one 1024-thread block per image (the statistics span the whole image):
+//   dx = rstd (g dy - mean(g dy) - xhat mean(g dy xhat)),  part[b][0][c] = sum_hw dy xhat,  part[b][1][c] = sum_hw dy
+__global__ __launch_bounds__(1024) void gn1_bwd_kernel(dig_gn1_bwd_args a) {
+    __shared__ float red[32];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const size_t base = (size_t)b * a.HW * a.C;
+    const float* x = a.x + base;
+    const float* dy = a.dy + base;
+    const float n = (float)a.HW * (float)a.C;
+    float s = 0.f;
+    for (int c = tid; c < a.C; c += 1024)
+        for (int p = 0; p < a.HW; p++) s += x[(size_t)p * a.C + c];
+    const float mu = block_sum(s, red) / n;
+    float v = 0.f;
+    for (int c = tid; c < a.C; c += 1024)
+        for (int p = 0; p < a.HW; p++) {
+            const float d = x[(size_t)p * a.C + c] - mu;
+            v += d * d;
+        }
+    const float rstd = rsqrtf(block_sum(v, red) / n + a.eps);
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = tid; c < a.C; c += 1024) {
+        const float g = a.gamma[c];
+        float dg = 0.f, db = 0.f;
+        for (int p = 0; p < a.HW; p++) {
+            const float d = dy[(size_t)p * a.C + c], xh = (x[(size_t)p * a.C + c] - mu) * rstd;
+            dg += d * xh;
+            db += d;
+        }
+        a.part[((size_t)b * 2) * a.C + c] = dg;
+        a.part[((size_t)b * 2 + 1) * a.C + c] = db;
+        s1 += g * db;
+        s2 += g * dg;
+    }
+    s1 = block_sum(s1, red) / n;
+    s2 = block_sum(s2, red) / n;
+    float* dx = a.dx + base;
+    for (int c = tid; c < a.C; c += 1024) {
+        const float g = a.gamma[c];
+        for (int p = 0; p < a.HW; p++) {
+            const size_t i = (size_t)p * a.C + c;
+            dx[i] = rstd * (g * dy[i] - s1 - (x[i] - mu) * rstd * s2);
+        }
+    }
+}
+
+// dx = dy * [y > 0] (y = the ReLU's output or input: same mask); dx may alias dy
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* y, const float* dy, float* dx, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+// d/d(student) of scale * KLDivLoss(batchmean, log_target)(log cat(S, 1-S), log cat(Tt, 1-Tt)), S = softmax(student / T),
+// Tt = softmax(teacher / T) (model.py:347-361; the teacher is detached): with a_c = -Tt_c / S_c + (1 - Tt_c) / (1 - S_c),
+//   dz_j = scale / (B T) * S_j (a_j - sum_c S_c a_c).  One wave per row.
+__global__ __launch_bounds__(256) void kd_bin_grad_kernel(dig_kd_bin_grad_args a) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= a.B) return;
+    const float* s = a.student + (size_t)b * a.C;
+    const float* t = a.teacher + (size_t)b * a.C;
+    float ms = -INFINITY, mt = -INFINITY;
+    for (int c = lane; c < a.C; c += 64) {
+        ms = fmaxf(ms, s[c] / a.T);
+        mt = fmaxf(mt, t[c] / a.T);
+    }
+    ms = wave_max(ms);
+    mt = wave_max(mt);
+    float zs = 0.f, zt = 0.f;
+    for (int c = lane; c < a.C; c += 64) {
+        zs += expf(s[c] / a.T - ms);
+        zt += expf(t[c] / a.T - mt);
+    }
+    zs = wave_sum(zs);
+    zt = wave_sum(zt);
+    float dot = 0.f;
+    for (int c = lane; c < a.C; c += 64) {
+        const float ps = expf(s[c] / a.T - ms) / zs, pt = expf(t[c] / a.T - mt) / zt;
+        dot += ps * (-pt / ps + (1.f - pt) / (1.f - ps));
+    }
+    dot = wave_sum(dot);
+    for (int c = lane; c < a.C; c += 64) {
+        const float ps = expf(s[c] / a.T - ms) / zs, pt = expf(t[c] / a.T - mt) / zt;
+        const float g = a.scale / ((float)a.B * a.T) * ps * ((-pt / ps + (1.f - pt) / (1.f - ps)) - dot);
+        a.dx[(size_t)b * a.C + c] = a.accumulate ? a.dx[(size_t)b * a.C + c] + g : g;
+    }
+}
+
 }  // namespace
 
 extern "C" int dig_gemm_f32(const dig_gemm_f32_args* a, void* stream_) {
@@ -553,5 +642,31 @@ extern "C" int dig_cam_fuse_bwd(const dig_cam_fuse_bwd_args* a, void* stream_) {
     const long long blocks = ((long long)a->B * a->C * a->P + 255) / 256;
     hipLaunchKernelGGL(cam_fuse_bwd_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream, *a);
     DIG_LAUNCH_CHECK("cam_fuse_bwd");
+    return DIG_OK;
+}
+
+extern "C" int dig_gn1_bwd(const dig_gn1_bwd_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->x && a->gamma && a->dy && a->dx && a->part, DIG_EINVAL, "gn1_bwd: null pointer");
+    DIG_CHECK(a->B > 0 && a->HW > 0 && a->C > 0 && a->eps > 0.f, DIG_EINVAL, "gn1_bwd: bad shape B=%d HW=%d C=%d", a->B, a->HW, a->C);
+    hipLaunchKernelGGL(gn1_bwd_kernel, dim3(a->B), dim3(1024), 0, stream, *a);
+    DIG_LAUNCH_CHECK("gn1_bwd");
+    return DIG_OK;
+}
+
+extern "C" int dig_relu_bwd(const dig_relu_bwd_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->y && a->dy && a->dx && a->n > 0, DIG_EINVAL, "relu_bwd: bad argument");
+    const long long blocks = (a->n + 255) / 256;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream, a->y, a->dy, a->dx, a->n);
+    DIG_LAUNCH_CHECK("relu_bwd");
+    return DIG_OK;
+}
+
+extern "C" int dig_kd_bin_grad(const dig_kd_bin_grad_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->student && a->teacher && a->dx && a->B > 0 && a->C > 0 && a->T > 0.f, DIG_EINVAL, "kd_bin_grad: bad argument");
+    hipLaunchKernelGGL(kd_bin_grad_kernel, dim3((a->B + 3) / 4), dim3(256), 0, stream, *a);
+    DIG_LAUNCH_CHECK("kd_bin_grad");
     return DIG_OK;
 }

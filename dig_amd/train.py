@@ -11,9 +11,9 @@ forward is re-run with its intermediates kept (`forward_train`), and `backward_c
 adjoint kernels of csrc/train.hip (dig_gemm_f32 with transposed operands as stride pairs, dig_layernorm_bwd, dig_gelu_bwd,
 dig_softmax_bwd, dig_head_pool_bwd, dig_msm_grad, dig_colsum); `AdamW` is torch.optim.AdamW's update with timm's no-decay
 filter.  fp32, eval-mode semantics (no DropPath / dropout: the product's MCTformer refuses drop rates), no atomics - a step is
-bitwise reproducible.  Built for every loss term that does not differentiate through the LFCA branch: loss_cls, loss_cls_diff,
-loss_cam_consistency (cam_diff enters detached) and loss_rcams_consistency (through the attention roll-up of all twelve layers);
-loss_pred_diff (the LFCA / distillation term) has forward kernels only (dig_amd/losses.py).
+bitwise reproducible.  All five loss terms are differentiated: loss_cls, loss_cls_diff, loss_cam_consistency (cam_diff enters
+detached), loss_rcams_consistency (through the attention roll-up of all twelve layers) and loss_pred_diff (the LFCA branch, on
+the tape of dig_amd/train_lfca.py).
 torch allocates, copies and reshapes; every arithmetic operation is a C-ABI launch.  There is no CPU fallback.
 """
 import math
@@ -324,27 +324,47 @@ def maxnorm_l1_bwd(a, b, label, scale, a_times_label):
     return db
 
 
-def update_step(m, opt, img, label, W=(1.0, 0.0, 1.0, 1.0, 10.0), img_diff=None, cam_diff=None, epo=10):
-    """One optimiser step of model_WSSS.update's MCTformer part (model.py:319-341,367-425) for the terms that do not
-    differentiate through the LFCA branch:
-        W[0] loss_cls + W[2] loss_cam_consistency (cam_diff = the LFCA output of this batch, a constant of the loss; epo > 9)
-        + W[3] loss_cls_diff + W[4] loss_rcams_consistency (both on img_diff, the t = 100 reconstruction; epo > 9)
-    W[1] (loss_pred_diff: soft-margin + distillation on the LFCA outputs) needs the LFCA backward, which is not built: a
-    non-zero W[1] raises.  zero_grad -> two forward passes with kept activations -> backward -> AdamW.
-    -> (loss_trm as a device scalar, grads)."""
-    from .losses import LFCA_EPOCH, _maxnorm_l1, _msm
-    if W[1] > 0:
-        raise NotImplementedError("dig_amd.train.update_step: W[1] > 0 (loss_pred_diff) needs the backward of the LFCA branch")
+def update_step(m, opt, img, label, W=(1.0, 1.0, 1.0, 1.0, 10.0), img_diff=None, feat_diff=None, cam_diff=None, epo=10, T=5.0, A=0.2):
+    """One optimiser step of model_WSSS.update's MCTformer part (model.py:319-425), all five terms:
+        W[0] loss_cls + W[1] loss_pred_diff (needs feat_diff, the five guidance maps: the LFCA branch runs on a tape,
+        dig_amd/train_lfca.py) + W[2] loss_cam_consistency (cam_diff = the LFCA output, a constant of the loss; epo > 9)
+        + W[3] loss_cls_diff + W[4] loss_rcams_consistency (both on img_diff, the t = 100 reconstruction; epo > 9).
+    zero_grad -> forward passes with kept activations -> backward -> AdamW.  cam_diff may be given (it is a constant) when
+    the LFCA branch is not run here (W[1] = 0).  -> (loss_trm as a device scalar, grads keyed like named_parameters())."""
+    from .losses import LFCA_EPOCH, _kd, _maxnorm_l1, _msm
     dev = img.device
     lab = label.to(dev).float().contiguous()
     B, C = lab.shape
     late = epo > LFCA_EPOCH
-    use_cam = W[2] > 0 and late and cam_diff is not None
+    if W[1] > 0 and feat_diff is None:
+        raise KeyError("dig_amd.train.update_step: W[1] > 0 (loss_pred_diff) needs feat_diff, the guidance maps of this batch")
+    use_lfca = W[1] > 0 or (W[2] > 0 and late and cam_diff is None and feat_diff is not None)
+    use_cam = W[2] > 0 and late and (cam_diff is not None or use_lfca)
     use_rc = W[4] > 0 and late and img_diff is not None
     outs, ctx = forward_train(m, img, want_cam=use_cam or use_rc)
     loss = torch.zeros(1, dtype=F32, device=dev)
     _msm(outs["cls"], lab, loss, W[0], False)
     _msm(outs["pcls"], lab, loss, W[0], True)
+    grads = None
+    if use_lfca:
+        from . import train_lfca
+        lo, lst = train_lfca.lfca_branch_train(m, ctx, feat_diff)
+        if cam_diff is None:
+            cam_diff = lo["cam_diff"]
+        if W[1] > 0:  # model.py:346-363; the teachers (cls / pcls of this pass) are constants
+            kd_scale = W[1] * (1 - A) * (T * T) * 0.5
+            _msm(lo["diff_cls"], lab, loss, W[1] * A, True)
+            _msm(lo["diff_pcls"], lab, loss, W[1] * A, True)
+            _kd(lo["diff_cls"], outs["cls"], loss, T, kd_scale, True)
+            _kd(lo["diff_pcls"], outs["pcls"], loss, T, kd_scale, True)
+            dd = []
+            for stu, tea in ((lo["diff_cls"], outs["cls"]), (lo["diff_pcls"], outs["pcls"])):
+                d = torch.empty(B, C, dtype=F32, device=dev)
+                call("msm_grad", x=stu, y=lab, dx=d, scale=float(W[1] * A), B=B, C=C)
+                call("kd_bin_grad", student=stu, teacher=tea, dx=d, T=float(T), scale=float(kd_scale), accumulate=1, B=B, C=C)
+                dd.append(d)
+            grads = dict(train_lfca.lfca_branch_backward(lst, dd[0], dd[1]))
+        del lst
     d_cams = None
     if use_cam:
         hw = outs["cams"].shape[2] * outs["cams"].shape[3]
@@ -353,7 +373,7 @@ def update_step(m, opt, img, label, W=(1.0, 0.0, 1.0, 1.0, 10.0), img_diff=None,
         _add_into(loss, term)
         d_cams = maxnorm_l1_bwd(cam_diff, outs["cams"], lab, W[2] / (B * C * hw), True)
     rc1 = outs["rcams"] if use_rc else None
-    grads = backward_cls(m, outs, ctx, lab, W[0], d_cams=d_cams)
+    grads = backward_cls(m, outs, ctx, lab, W[0], grads=grads, d_cams=d_cams)
     del ctx
     if img_diff is not None and (W[3] > 0 or use_rc):
         outs2, ctx2 = forward_train(m, img_diff, want_cam=use_rc)

@@ -749,6 +749,39 @@ typedef struct {
 } dig_cam_fuse_bwd_args;
 int dig_cam_fuse_bwd(const dig_cam_fuse_bwd_args* a, void* stream);
 
+/* adjoint of nn.GroupNorm(1, C) (LFCA.norm_p1 mctformer.py:70,164; ResBlock_ysh's norms resnet101.py:31-38) on NHWC x [B][HW][C]:
+ * dx [B][HW][C]; part [B][2][C] = per-image sums of dy*xhat (dgamma) and dy (dbeta), finished by dig_colsum over the batch */
+typedef struct {
+    const float* x;
+    const float* gamma;
+    const float* dy;
+    float* dx;
+    float* part;
+    int B, HW, C;
+    float eps;
+} dig_gn1_bwd_args;
+int dig_gn1_bwd(const dig_gn1_bwd_args* a, void* stream);
+
+/* adjoint of ReLU: dx = dy * [y > 0] (y: the ReLU's output or its input); dx may alias dy */
+typedef struct {
+    const float* y;
+    const float* dy;
+    float* dx;
+    long long n;
+} dig_relu_bwd_args;
+int dig_relu_bwd(const dig_relu_bwd_args* a, void* stream);
+
+/* dx (+)= d/d(student) of scale * the binary-split distillation term of dig_kd_bin_loss (model.py:347-361; the teacher logits
+ * enter detached): student, teacher, dx [B][C] */
+typedef struct {
+    const float* student;
+    const float* teacher;
+    float* dx;
+    float T, scale;
+    int accumulate, B, C;
+} dig_kd_bin_grad_args;
+int dig_kd_bin_grad(const dig_kd_bin_grad_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -373,8 +373,8 @@ def mctformer_cam(sd, img, n_layers=12, heads=6, patch=16, collect=None):
     if collect is not None:
         collect["tokens"] = x
         # the LFCA queries, mctformer.py:279-281: q of the last / second-to-last block as [B, C+N, D]
-        collect["query0"] = qs[-1].permute(0, 2, 1, 3).reshape(B, -1, D)
-        collect["query1"] = qs[-2].permute(0, 2, 1, 3).reshape(B, -1, D)
+        collect["query0"] = qs[-1].permute(0, 2, 1, 3).reshape(B, -1, D).detach()  # (.detach(): mctformer.py:280-281 - the LFCA
+        collect["query1"] = qs[-2].permute(0, 2, 1, 3).reshape(B, -1, D).detach()  #  branch sends no gradient into the ViT)
     # no final self.norm in the DiG subclass (mctformer.py:242-250)
     xp = x[:, C:].reshape(B, hp, wp, D).permute(0, 3, 1, 2).contiguous()
     head = F.conv2d(xp, sd["head.weight"], sd["head.bias"], padding=1)
@@ -518,6 +518,44 @@ def mct_consistency_loss_grads(sd, img, img_diff, cam_diff, label, W=(1.0, 0.0, 
         names = [k for k in leaves]
         grads = torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)
     return float(loss.detach()), {k: g for k, g in zip(names, grads) if g is not None}
+
+
+def mct_update_loss_grads(sd, img, feat_diff, img_diff, label, W=(1.0, 1.0, 1.0, 1.0, 10.0), T=5.0, A=0.2, epo=10):
+    """loss_trm.backward() of model_WSSS.update (model.py:322-424) with ALL five terms, by autograd over this file's forward
+    restatement: first pass with the LFCA branch (its ViT queries detached, mctformer.py:280-281; teachers and cam_diff detached,
+    model.py:349-350,389), second pass on img_diff.  sd must hold the LFCA0 / LFCA1 / diff_head_p parameters.
+    -> (loss_trm, {state_dict key: gradient})."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
+    with torch.enable_grad():
+        o1 = mctformer_outputs(leaves, img, feat_diff)
+        o2 = mctformer_outputs(leaves, img_diff)
+        loss = _update_loss_tensor(o1, o2, label, W, T, A, epo)
+        names = [k for k in leaves]
+        grads = torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)
+    return float(loss.detach()), {k: g for k, g in zip(names, grads) if g is not None}
+
+
+def _update_loss_tensor(o1, o2, label, W, T, A, epo, lfca_epoch=9):
+    """loss_trm of model.py:337-421 as a differentiable tensor (update_losses above returns floats), same expressions."""
+    B, C = label.shape
+    kd_log = torch.nn.KLDivLoss(reduction="batchmean", log_target=True)
+    msm = F.multilabel_soft_margin_loss
+    lab4 = label.view(B, C, 1, 1)
+    loss = W[0] * (msm(o1["cls"], label) + msm(o1["pcls"], label))
+    if W[1] > 0:
+        sp, sc = F.softmax(o1["diff_pcls"] / T, dim=1), F.softmax(o1["diff_cls"] / T, dim=1)
+        tp, tc = F.softmax(o1["pcls"].detach() / T, dim=1), F.softmax(o1["cls"].detach() / T, dim=1)
+        lg = lambda p: torch.log(torch.cat((p, 1 - p), dim=1))
+        loss = loss + W[1] * (A * msm(o1["diff_cls"], label) + A * msm(o1["diff_pcls"], label)
+                              + (1 - A) * (T * T) * kd_log(lg(sc), lg(tc)) * 0.5 + (1 - A) * (T * T) * kd_log(lg(sp), lg(tp)) * 0.5)
+    if W[2] > 0 and epo > lfca_epoch:
+        _cams = max_norm(F.interpolate(o1["cams"], size=o1["cam_diff"].shape[2:], mode="bilinear", align_corners=False))
+        loss = loss + W[2] * (((max_norm(o1["cam_diff"]) * lab4).detach() - _cams) * lab4).abs().mean()
+    if W[3] > 0 or W[4] > 0:
+        loss = loss + W[3] * (msm(o2["cls"], label) + msm(o2["pcls"], label))
+    if W[4] > 0 and epo > lfca_epoch:
+        loss = loss + W[4] * ((max_norm(o1["rcams"]).detach() - max_norm(o2["rcams"])) * lab4).abs().mean()
+    return loss
 
 
 def adamw_no_decay(name, p):

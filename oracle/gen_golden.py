@@ -382,6 +382,40 @@ def case_grads_consistency(mct, name, C, H, W, B, hd, wd, Wt=(1.0, 0.0, 1.0, 1.0
     save(name, **arrays)
 
 
+def case_grads_update(mct, name, C, H, W, B, hd, wd, Wt=(1.0, 1.0, 1.0, 1.0, 10.0), T=5.0, A=0.2):
+    """(f)-4: loss_trm.backward() of the REFERENCE with all five terms of model.py:337-421 (epo past the LFCA gate): two
+    reference MCTformer passes in eval mode, the reference's own loss expressions (the oracle's _update_loss_tensor restates
+    them; the value is compared), .grad of EVERY parameter - ViT, LFCA0 / LFCA1, diff_head_p - as norm / sum / 256 sampled entries."""
+    m = mct.deit_small_MCTformerV2_DiG(num_classes=C).eval()
+    synth.fill_state_dict(m, seed=0, skip_prefixes=("norm.",))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    img = synth.synth_imagenet_images(B, H, W, seed=6300)
+    img_diff = synth.synth_imagenet_images(B, H, W, seed=6301)
+    label = synth.synth_labels(B, C, seed=15)
+    feat = [synth.normal("feat_diff", (B, 1024, hd, wd), seed=37 + j) * 1.5 for j in range(5)]
+    with torch.enable_grad():
+        for p in m.parameters():
+            p.requires_grad_(True)
+        o1 = m(img, feat_diff=feat)
+        o2 = m(img_diff)
+        loss = O._update_loss_tensor(o1, o2, label, Wt, T, A, 10)
+        loss.backward()
+    ref = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    lo, og = O.mct_update_loss_grads(sd, img, feat, img_diff, label, Wt, T, A, 10)
+    assert set(og) == set(ref), sorted(set(og) ^ set(ref))
+    rel = max(float((og[k] - ref[k]).norm() / (ref[k].norm() + 1e-30)) for k in ref)
+    arrays = {"label": label, "loss": np.float64(float(loss)), "W": np.array(Wt, np.float64), "T": np.float64(T), "A": np.float64(A)}
+    names = sorted(ref)
+    arrays["names"] = np.array(names)
+    for i, k in enumerate(names):
+        idx = synth.sample_index(k, ref[k].numel())
+        arrays[f"g{i}_norm"] = np.float64(float(ref[k].double().norm()))
+        arrays[f"g{i}_sum"] = np.float64(float(ref[k].double().sum()))
+        arrays[f"g{i}_s"] = ref[k].flatten()[idx]
+    record(name, loss=abs(lo - float(loss)), grad_rel=rel)
+    save(name, **arrays)
+
+
 def synth_eval_set(C=20, seed=5):
     """Small synthetic CAM dicts + ground-truth maps (with 255 boundary pixels) for the evaluation cases."""
     rng = np.random.RandomState(seed)
@@ -516,6 +550,7 @@ def main():
     if sys.argv[1:] == ["grads"]:  # (f)-4: the reference's own .grad tensors (sampled) + one AdamW step
         case_grads(mct, "grads224_c20", 20, 224, 224, 2)
         case_grads_consistency(mct, "grads_consistency224_c20", 20, 224, 224, 2, 14, 14)
+        case_grads_update(mct, "grads_update224_c20", 20, 224, 224, 2, 14, 14)
         _merge_manifest()
         return
     if sys.argv[1:] == ["eval"]:
@@ -536,6 +571,7 @@ def main():
     case_envelope_full(ddp, "unet256_t100_img0", 256, 256, 0)
     case_grads(mct, "grads224_c20", 20, 224, 224, 2)
     case_grads_consistency(mct, "grads_consistency224_c20", 20, 224, 224, 2, 14, 14)
+    case_grads_update(mct, "grads_update224_c20", 20, 224, 224, 2, 14, 14)
     case_lfca(mct, "lfca224_c20", 20, 224, 224, 14, 14)
     case_lfca(mct, "lfca224_c20_maps16", 20, 224, 224, 16, 16)  # guidance maps from a 256x256 diffusion input: bilinear 14 -> 16
     case_eval(ref_import.load_evaluation())

@@ -36,6 +36,9 @@ def test_manifest_pins_oracle():
         for k, v in d.items():
             if k == "argmax_flips":
                 assert v == 0
+            elif k == "adamw_update_over_lr":
+                # |p_oracle - p_reference| / lr after one AdamW step: one fp32 ulp of a parameter (6e-8 at |p| ~ 1) over lr
+                assert v <= 1e-3, (case, k, v)
             else:
                 assert v <= 1.5e-5, (case, k, v)
 
