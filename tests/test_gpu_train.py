@@ -23,6 +23,13 @@ DEV = "cuda"
 F32 = torch.float32
 
 
+@pytest.fixture(autouse=True)
+def _autograd_on():
+    """the torch-autograd references of this file need grad mode, which other test modules switch off process-wide at import"""
+    with torch.enable_grad():
+        yield
+
+
 def T(a):
     return torch.from_numpy(np.asarray(a))
 
