@@ -74,8 +74,9 @@ class MCTformerV2_DiG(nn.Module):
     diff_head_p under the reference's names, so `load_state_dict(torch.load('{epo:03d}net_trm.pth'))` (model.py:214-218)
     works strictly, and forward(x, feat_diff=[5 x [B,1024,h,w]]) runs the LFCA consumer in eval mode.  `lfca=False` is an
     explicit opt-out that saves the 191 M LFCA parameters for CAM-only inference (then load checkpoints with strict=False).
-    Stochastic depth / dropout (drop_path_rate, drop_rate) are training features and are not implemented: forward() in
-    training mode raises instead of silently running without them."""
+    forward() is the inference product: in training mode with a drop rate set it raises instead of silently running without
+    stochastic depth.  Training goes through dig_amd.train.update_step, which takes the DropPath factors of a step explicitly
+    (train.draw_drop_path reads drop_path_rate from here); dropout (drop_rate, 0 in the reference's configuration) is not built."""
 
     def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=20, embed_dim=384, depth=12, num_heads=6,
                  mlp_ratio=4., lfca=True, drop_rate=0., drop_path_rate=0., **_ignored):
@@ -105,7 +106,8 @@ class MCTformerV2_DiG(nn.Module):
         if self.training and (self.drop_path_rate > 0 or self.drop_rate > 0 or feat_diff is not None):
             # the reference trains with DropPath(drop_path_rate) in every block and DropPath(0.1) inside LFCA
             # (vision_transformer.py:184-186, mctformer.py:93,163-164); this build is forward-only
-            raise NotImplementedError("dig_amd.MCTformerV2_DiG is forward-only (no DropPath / dropout): call .eval() first")
+            raise NotImplementedError("dig_amd.MCTformerV2_DiG.forward is the inference path (no DropPath / dropout): call .eval() first; "
+                                      "training steps go through dig_amd.train.update_step(..., drop_path=train.draw_drop_path(...))")
         if feat_diff is not None and not self.has_lfca:
             raise RuntimeError("this model was built with lfca=False: no LFCA0/LFCA1/diff_head_p parameters")
         outs = cam.mctformer_forward(self, x, n_layers, feat_diff=feat_diff)

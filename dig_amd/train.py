@@ -96,10 +96,49 @@ def layernorm_bwd(x, gamma, dy, add=None, eps=1e-6):
     return dx, gb[:D], gb[D:]
 
 
-def forward_train(m, img, want_cam=False):
+def _dp_apply(u, s, res=None):
+    """s_b * u (+ res): a DropPath factor per sample (mask_b / keep_prob) on a branch output u [B, ..., C], as the [B][C][2]
+    (scale, shift) table of dig_affine_act_add"""
+    from .cam import _affine
+    B, C = u.shape[0], u.shape[-1]
+    tab = torch.zeros(B, C, 2, dtype=F32, device=u.device)
+    tab[..., 0] = s.to(device=u.device, dtype=F32).reshape(B, 1)
+    r3 = None if res is None else res.reshape(B, -1, C)
+    return _affine(u.reshape(B, -1, C).contiguous(), tab, res=r3).reshape(u.shape)
+
+
+def draw_drop_path(m, B, device, lfca=True, passes=2, generator=None, lfca_rate=0.1):
+    """The stochastic-depth factors of one update step, drawn as timm's DropPath draws them (per sample Bernoulli(keep_prob),
+    divided by keep_prob; timm 0.3.x is not importable here: the rule is restated and PARITY UNPINNED on the random stream -
+    the arithmetic with given factors is pinned, tests/test_gpu_train.py).  Block i of the ViT has rate
+    linspace(0, m.drop_path_rate, depth)[i] (vision_transformer.py:265; rate 0 = nn.Identity, no draw), both branches of a
+    block draw separately (:193-194); each LFCA has DropPath(0.1) on its two patch-branch residuals (mctformer.py:93,163-164)
+    in the first pass only.  -> the `drop_path` argument of update_step, or None when nothing would be dropped."""
+    rate = float(getattr(m, "drop_path_rate", 0.0) or 0.0)
+    depth = len(m.blocks)
+    rates = [float(r) for r in torch.linspace(0, rate, depth)]  # the reference's expression: fp32 values, .item()
+
+    def draw(r):
+        keep = 1.0 - r
+        return (torch.rand(B, device=device, generator=generator) < keep).to(F32) / keep
+
+    if rate <= 0.0 and not lfca:
+        return None
+    out = {}
+    for ps in range(1, passes + 1):
+        out[f"pass{ps}"] = {"blocks": [(draw(r), draw(r)) if r > 0 else (None, None) for r in rates]}
+    if lfca:
+        out["pass1"]["LFCA0"] = (draw(lfca_rate), draw(lfca_rate))
+        out["pass1"]["LFCA1"] = (draw(lfca_rate), draw(lfca_rate))
+    return out
+
+
+def forward_train(m, img, want_cam=False, dp=None):
     """MCTformerV2_DiG.forward without the LFCA branch (mctformer.py:227-263,293-300,318), keeping what the backward needs.
     -> (outs {cls, pcls}, ctx); want_cam adds the CAM outputs the consistency terms use (cams = relu(head), mtatt, fcams, rcams:
-    mctformer.py:302-321,334-338) from the head-averaged, layer-summed roll-up of the kept attention probabilities."""
+    mctformer.py:302-321,334-338) from the head-averaged, layer-summed roll-up of the kept attention probabilities.
+    dp: train-mode DropPath, [(s_attn, s_mlp)] per block, each a [B] tensor of mask / keep_prob or None (see draw_drop_path);
+    None = eval-mode semantics."""
     if not img.is_cuda:
         raise RuntimeError("dig_amd.train runs on the HIP device only (no CPU fallback)")
     P = _pack(m)
@@ -122,7 +161,10 @@ def forward_train(m, img, want_cam=False):
                 batch=B, sa=(Pn * 3 * ps * ps, 0), sc=(N * D, 0), sr=(0, 0))
     saved = []
     acc = torch.zeros(B, N, N, dtype=F32, device=dev) if want_cam else None
-    for bp in P["blocks"]:
+    if dp is not None and len(dp) != len(P["blocks"]):
+        raise ValueError(f"dig_amd.train.forward_train: {len(dp)} DropPath entries for {len(P['blocks'])} blocks")
+    for li, bp in enumerate(P["blocks"]):
+        s1, s2 = dp[li] if dp is not None else (None, None)
         x0 = x
         y1 = _layernorm(x0, bp["n1"])
         qkv = ops.linear_rows(y1, bp["qkv"][0], bias=bp["qkv"][1])
@@ -135,13 +177,19 @@ def forward_train(m, img, want_cam=False):
         o = torch.empty(B, N, D, dtype=F32, device=dev)
         gemm_f32(Pm, (qkv, 2 * D), o, N, dh, N, sam=N, sak=1, sbk=3 * D, sbn=1, ldc=D, batch=B * heads, z_inner=heads,
                  sa=(heads * N * N, N * N), sb=(N * 3 * D, dh), sc=(N * D, dh))
-        x1 = ops.linear_rows(o, bp["proj"][0], bias=bp["proj"][1], res=x0)
+        if s1 is None:
+            x1 = ops.linear_rows(o, bp["proj"][0], bias=bp["proj"][1], res=x0)
+        else:  # x + drop_path(attn(norm1(x))), vision_transformer.py:193
+            x1 = _dp_apply(ops.linear_rows(o, bp["proj"][0], bias=bp["proj"][1]), s1, res=x0)
         y2 = _layernorm(x1, bp["n2"])
         pre = ops.linear_rows(y2, bp["fc1"][0], bias=bp["fc1"][1])
         hdn = torch.empty_like(pre)
         call("act", **{"in": pre}, out=hdn, n=pre.numel(), act=1, in_f32=1, out_f32=1, dtype=1)
-        x = ops.linear_rows(hdn, bp["fc2"][0], bias=bp["fc2"][1], res=x1)
-        saved.append(dict(x0=x0, y1=y1, qkv=qkv, P=Pm, o=o, x1=x1, y2=y2, pre=pre, h=hdn))
+        if s2 is None:
+            x = ops.linear_rows(hdn, bp["fc2"][0], bias=bp["fc2"][1], res=x1)
+        else:  # x + drop_path(mlp(norm2(x))), vision_transformer.py:194
+            x = _dp_apply(ops.linear_rows(hdn, bp["fc2"][0], bias=bp["fc2"][1]), s2, res=x1)
+        saved.append(dict(x0=x0, y1=y1, qkv=qkv, P=Pm, o=o, x1=x1, y2=y2, pre=pre, h=hdn, s1=s1, s2=s2))
     head = torch.empty(B, hp, wp, C, dtype=F32, device=dev)
     call("conv3x3", in0=x.data_ptr() + C * D * 4, in1=None, aff0=None, w=P["head"].w, bias=P["head"].bias, out=head, stats=None,
          in0_bstride=N * D, B=B, H=hp, W=wp, C0=D, C1=0, Cout=C, groups=1, up2=0, dtype=1)
@@ -226,14 +274,17 @@ def backward_cls(m, outs, ctx, label, weight=1.0, grads=None, d_cams=None, d_rca
     for li in range(len(P["blocks"]) - 1, -1, -1):
         bp, sv = P["blocks"][li], ctx["saved"][li]
         pre = f"blocks.{li}."
-        dh_, dw, db = linear_bwd(sv["h"].reshape(M, -1), bp["fc2"][0], dx.reshape(M, D), M)
+        # a dropped branch: its gradient is the residual stream's times the same per-sample factor; the stream itself passes
+        dbr = dx if sv["s2"] is None else _dp_apply(dx, sv["s2"])
+        dh_, dw, db = linear_bwd(sv["h"].reshape(M, -1), bp["fc2"][0], dbr.reshape(M, D), M)
         new[pre + "mlp.fc2.weight"], new[pre + "mlp.fc2.bias"] = dw, db
         call("gelu_bwd", x=sv["pre"], dy=dh_, dx=dh_, n=dh_.numel())
         dy2, dw, db = linear_bwd(sv["y2"].reshape(M, D), bp["fc1"][0], dh_, M)
         new[pre + "mlp.fc1.weight"], new[pre + "mlp.fc1.bias"] = dw, db
         dx1, dg, dbt = layernorm_bwd(sv["x1"], bp["n2"][0], dy2.reshape(B, N, D), add=dx)
         new[pre + "norm2.weight"], new[pre + "norm2.bias"] = dg.clone(), dbt.clone()
-        do, dw, db = linear_bwd(sv["o"].reshape(M, D), bp["proj"][0], dx1.reshape(M, D), M)
+        dbr = dx1 if sv["s1"] is None else _dp_apply(dx1, sv["s1"])
+        do, dw, db = linear_bwd(sv["o"].reshape(M, D), bp["proj"][0], dbr.reshape(M, D), M)
         new[pre + "attn.proj.weight"], new[pre + "attn.proj.bias"] = dw, db
         # attention (vision_transformer.py:87-97): per (image, head) on the q | k | v thirds of qkv, gradients into dqkv
         qkv, Pm = sv["qkv"], sv["P"]
@@ -324,13 +375,17 @@ def maxnorm_l1_bwd(a, b, label, scale, a_times_label):
     return db
 
 
-def update_step(m, opt, img, label, W=(1.0, 1.0, 1.0, 1.0, 10.0), img_diff=None, feat_diff=None, cam_diff=None, epo=10, T=5.0, A=0.2):
+def update_step(m, opt, img, label, W=(1.0, 1.0, 1.0, 1.0, 10.0), img_diff=None, feat_diff=None, cam_diff=None, epo=10, T=5.0, A=0.2,
+                drop_path=None):
     """One optimiser step of model_WSSS.update's MCTformer part (model.py:319-425), all five terms:
         W[0] loss_cls + W[1] loss_pred_diff (needs feat_diff, the five guidance maps: the LFCA branch runs on a tape,
         dig_amd/train_lfca.py) + W[2] loss_cam_consistency (cam_diff = the LFCA output, a constant of the loss; epo > 9)
         + W[3] loss_cls_diff + W[4] loss_rcams_consistency (both on img_diff, the t = 100 reconstruction; epo > 9).
     zero_grad -> forward passes with kept activations -> backward -> AdamW.  cam_diff may be given (it is a constant) when
-    the LFCA branch is not run here (W[1] = 0).  -> (loss_trm as a device scalar, grads keyed like named_parameters())."""
+    the LFCA branch is not run here (W[1] = 0).  drop_path: the stochastic-depth factors of this step (draw_drop_path; the
+    reference runs update() in train mode with drop_path_rate 0.1, train_trm.py:158, model.py:320) - None = eval-mode semantics.
+    -> (loss_trm as a device scalar, grads keyed like named_parameters())."""
+    dp1, dp2 = (drop_path or {}).get("pass1") or {}, (drop_path or {}).get("pass2") or {}
     from .losses import LFCA_EPOCH, _kd, _maxnorm_l1, _msm
     dev = img.device
     lab = label.to(dev).float().contiguous()
@@ -341,14 +396,14 @@ def update_step(m, opt, img, label, W=(1.0, 1.0, 1.0, 1.0, 10.0), img_diff=None,
     use_lfca = W[1] > 0 or (W[2] > 0 and late and cam_diff is None and feat_diff is not None)
     use_cam = W[2] > 0 and late and (cam_diff is not None or use_lfca)
     use_rc = W[4] > 0 and late and img_diff is not None
-    outs, ctx = forward_train(m, img, want_cam=use_cam or use_rc)
+    outs, ctx = forward_train(m, img, want_cam=use_cam or use_rc, dp=dp1.get("blocks"))
     loss = torch.zeros(1, dtype=F32, device=dev)
     _msm(outs["cls"], lab, loss, W[0], False)
     _msm(outs["pcls"], lab, loss, W[0], True)
     grads = None
     if use_lfca:
         from . import train_lfca
-        lo, lst = train_lfca.lfca_branch_train(m, ctx, feat_diff)
+        lo, lst = train_lfca.lfca_branch_train(m, ctx, feat_diff, dp=dp1)
         if cam_diff is None:
             cam_diff = lo["cam_diff"]
         if W[1] > 0:  # model.py:346-363; the teachers (cls / pcls of this pass) are constants
@@ -376,7 +431,7 @@ def update_step(m, opt, img, label, W=(1.0, 1.0, 1.0, 1.0, 10.0), img_diff=None,
     grads = backward_cls(m, outs, ctx, lab, W[0], grads=grads, d_cams=d_cams)
     del ctx
     if img_diff is not None and (W[3] > 0 or use_rc):
-        outs2, ctx2 = forward_train(m, img_diff, want_cam=use_rc)
+        outs2, ctx2 = forward_train(m, img_diff, want_cam=use_rc, dp=dp2.get("blocks"))
         _msm(outs2["cls"], lab, loss, W[3], True)
         _msm(outs2["pcls"], lab, loss, W[3], True)
         d_rc = None

@@ -6,7 +6,7 @@ run on a small tape: every forward helper enqueues its launches, keeps what its 
 tape; `Tape.backward()` replays them in reverse.  Gradients are keyed by the data pointer of the (contiguous, owned) tensor
 they belong to; parameter gradients accumulate under the reference's state_dict names (norm_k is applied twice per LFCA).
 The ViT queries enter detached (mctformer.py:280-281) and the guidance maps are data: nothing flows out of the branch, its
-gradients are those of LFCA0 / LFCA1 / diff_head_p only.  fp32, eval-mode semantics (DropPath = identity), map sizes of the
+gradients are those of LFCA0 / LFCA1 / diff_head_p only.  fp32; DropPath with given per-sample factors (dpath) or eval-mode semantics; map sizes of the
 ViT grid and the guidance maps equal (the bilinear resize of mctformer.py:161 is then the identity; its adjoint is not built).
 torch allocates, copies and reshapes; all arithmetic is C-ABI launches.
 """
@@ -15,7 +15,7 @@ import torch
 from . import ops
 from ._lib import call
 from .cam import _affine, _layernorm
-from .train import F32, _add_into, _ksplit, colsum, gemm_f32, layernorm_bwd, linear_bwd
+from .train import F32, _add_into, _dp_apply, _ksplit, colsum, gemm_f32, layernorm_bwd, linear_bwd
 
 
 class Tape:
@@ -196,6 +196,18 @@ def add(tp, a, b, sa=1.0, sb=1.0):
     return y
 
 
+def dpath(tp, x, s):
+    """DropPath in train mode with its draw given (mctformer.py:163-164): y = s_b * x, s_b = mask_b / keep_prob; s None = identity"""
+    if s is None:
+        return x
+    y = _dp_apply(x, s)
+
+    def bwd():
+        tp.acc(x, _dp_apply(tp.grad(y).contiguous(), s))
+    tp.ops.append(bwd)
+    return y
+
+
 def xattn(tp, q, k, v, heads, scale):
     """multi-head cross attention (mctformer.py:138-151): q [B,Nq,D], k [B,Nf,D], v [B,Nf,Df] -> o [B,Nq,Df]"""
     B, Nq, D = q.shape
@@ -227,8 +239,8 @@ def xattn(tp, q, k, v, heads, scale):
     return o
 
 
-def lfca_train(tp, L, prefix, qin, C, feat):
-    """LFCA.forward (mctformer.py:124-166), eval semantics, on the tape.  qin [B,Nq,D]: the (detached) query of a ViT block;
+def lfca_train(tp, L, prefix, qin, C, feat, dp=(None, None)):
+    """LFCA.forward (mctformer.py:124-166) on the tape; dp = the DropPath factors of :163 and :164 (None: eval semantics).  qin [B,Nq,D]: the (detached) query of a ViT block;
     feat NHWC [B,hd,wd,5*Df] fp32.  -> (x_c [B,C,D], x_p NHWC [B,hd,wd,Df])."""
     B, Nq, D = qin.shape
     N = Nq - C
@@ -267,14 +279,14 @@ def lfca_train(tp, L, prefix, qin, C, feat):
     x_c = add(tp, lin(tp, hdn, L.mlp_c1[2].weight, L.mlp_c1[2].bias, prefix + "mlp_c1.2"), x_c)
     # patch branch (mctformer.py:160-164); equal map sizes: F.interpolate is the identity
     o_p = conv3(tp, o_p, L.mlp_p0.weight, L.mlp_p0.bias, prefix + "mlp_p0")
-    x_p = add(tp, kv, o_p)
+    x_p = add(tp, kv, dpath(tp, o_p, dp[0]))
     y = gn1(tp, x_p, L.norm_p1, prefix + "norm_p1", 1e-6)
     hdn = gelu(tp, lin(tp, y.reshape(-1, Df), L.mlp_p1[0].weight, L.mlp_p1[0].bias, prefix + "mlp_p1.0"))
-    x_p = add(tp, lin(tp, hdn, L.mlp_p1[2].weight, L.mlp_p1[2].bias, prefix + "mlp_p1.2").reshape(x_p.shape), x_p)
+    x_p = add(tp, dpath(tp, lin(tp, hdn, L.mlp_p1[2].weight, L.mlp_p1[2].bias, prefix + "mlp_p1.2").reshape(x_p.shape), dp[1]), x_p)
     return x_c.reshape(B, C, D), x_p
 
 
-def lfca_branch_train(m, ctx, feat_diff):
+def lfca_branch_train(m, ctx, feat_diff, dp=None):
     """The LFCA branch of MCTformerV2_DiG.forward (mctformer.py:265-291,324-346) on a tape, from the kept qkv of the last two
     ViT blocks of a forward_train pass.  -> (outs {cam_diff, diff_cls, diff_pcls}, tape state for lfca_branch_backward)."""
     B, C, D, heads, dh, hp, wp, Pn, N, ps = ctx["dims"]
@@ -285,8 +297,9 @@ def lfca_branch_train(m, ctx, feat_diff):
     tp = Tape()
     q0 = ctx["saved"][-1]["qkv"][..., :D].contiguous()   # query0 = q of the last block, query1 = of the one before (:279-281)
     q1 = ctx["saved"][-2]["qkv"][..., :D].contiguous()
-    c0, p0 = lfca_train(tp, m.LFCA0, "LFCA0.", q0, C, feat)
-    c1, p1 = lfca_train(tp, m.LFCA1, "LFCA1.", q1, C, feat)
+    dp = dp or {}
+    c0, p0 = lfca_train(tp, m.LFCA0, "LFCA0.", q0, C, feat, dp=dp.get("LFCA0", (None, None)))
+    c1, p1 = lfca_train(tp, m.LFCA1, "LFCA1.", q1, C, feat, dp=dp.get("LFCA1", (None, None)))
     out_c = add(tp, c0, c1, 0.5, 0.5)
     out_p = add(tp, p0, p1, 0.5, 0.5)
     hh = relu(tp, conv3(tp, out_p, m.diff_head_p[0].weight, m.diff_head_p[0].bias, "diff_head_p.0"))

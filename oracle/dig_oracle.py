@@ -336,22 +336,31 @@ def vit_pos_embed(sd, num_classes, H, W, patch=16):
     return torch.cat([pe[:, :num_classes], pp], dim=1)
 
 
-def vit_block(w, x, heads, want_q=False):
+def drop_path_apply(t, s):
+    """DropPath in train mode with its Bernoulli draw GIVEN: t * s_b, s_b = mask_b / keep_prob per sample (timm.models.layers
+    DropPath / drop_path with scale_by_keep, timm 0.3.x as the DiG repo pins it; timm is not importable here, so the rule is
+    restated: the random DRAW is parity-unpinned, the arithmetic is pinned by the reference's own block code run with the same
+    factors - oracle/gen_golden.py case_grads_update_droppath).  s None = eval mode / rate 0 (identity)."""
+    return t if s is None else t * s.view(-1, *([1] * (t.dim() - 1)))
+
+
+def vit_block(w, x, heads, want_q=False, dp=(None, None)):
     """Block + Attention + Mlp, vision_transformer.py:54-103,177-196.  Returns (x, probs) or, with want_q,
-    (x, probs, q) where q is the un-scaled query [B, heads, N, D/heads] that Attention.forward hands back (:96-103)."""
+    (x, probs, q) where q is the un-scaled query [B, heads, N, D/heads] that Attention.forward hands back (:96-103).
+    dp = (s_attn, s_mlp): train-mode DropPath factors of the two residual branches (:193-194), see drop_path_apply."""
     B, N, D = x.shape
     y = F.layer_norm(x, (D,), w["norm1.weight"], w["norm1.bias"], eps=1e-6)
     qkv = F.linear(y, w["attn.qkv.weight"], w["attn.qkv.bias"]).reshape(B, N, 3, heads, D // heads)
     q, k, v = qkv.permute(2, 0, 3, 1, 4)
     p = ((q @ k.transpose(-2, -1)) * (D // heads) ** -0.5).softmax(dim=-1)
     o = (p @ v).transpose(1, 2).reshape(B, N, D)
-    x = x + F.linear(o, w["attn.proj.weight"], w["attn.proj.bias"])
+    x = x + drop_path_apply(F.linear(o, w["attn.proj.weight"], w["attn.proj.bias"]), dp[0])
     y = F.layer_norm(x, (D,), w["norm2.weight"], w["norm2.bias"], eps=1e-6)
-    y = F.linear(F.gelu(F.linear(y, w["mlp.fc1.weight"], w["mlp.fc1.bias"])), w["mlp.fc2.weight"], w["mlp.fc2.bias"])
+    y = drop_path_apply(F.linear(F.gelu(F.linear(y, w["mlp.fc1.weight"], w["mlp.fc1.bias"])), w["mlp.fc2.weight"], w["mlp.fc2.bias"]), dp[1])
     return (x + y, p, q) if want_q else (x + y, p)
 
 
-def mctformer_cam(sd, img, n_layers=12, heads=6, patch=16, collect=None):
+def mctformer_cam(sd, img, n_layers=12, heads=6, patch=16, collect=None, dp=None):
     """MCTformerV2_DiG.forward(x, return_att=True) -> rcams, mctformer.py:227-263,293-321,347-348.
     Also returns the intermediates the product exposes (mtatt, patch_attn, relu(head))."""
     B, _, H, W = img.shape
@@ -367,7 +376,7 @@ def mctformer_cam(sd, img, n_layers=12, heads=6, patch=16, collect=None):
     probs = []
     qs = []
     for i in range(depth):
-        x, p, q = vit_block(_sub(sd, f"blocks.{i}."), x, heads, want_q=True)
+        x, p, q = vit_block(_sub(sd, f"blocks.{i}."), x, heads, want_q=True, dp=dp[i] if dp is not None else (None, None))
         probs.append(p.mean(dim=1))  # head mean, mctformer.py:303
         qs.append(q)
     if collect is not None:
@@ -402,8 +411,8 @@ def res_block_ysh(w, x):
     return F.relu(y + F.conv2d(x, w["branch.weight"]))
 
 
-def lfca(w, query_vit, feat_cat, C, heads=8):
-    """LFCA.forward in eval mode (DropPath = identity), mctformer.py:124-166.
+def lfca(w, query_vit, feat_cat, C, heads=8, dp=(None, None)):
+    """LFCA.forward, mctformer.py:124-166; dp = the two train-mode DropPath factors of :163-164 (None: eval mode, identity).
     query_vit [B, C+N, D]; feat_cat [B, 5*D_f, h, w] -> (x_c [B, C, D], x_p [B, D_f, h, w])."""
     B, _, hd, wd = feat_cat.shape
     D = query_vit.shape[-1]
@@ -428,23 +437,24 @@ def lfca(w, query_vit, feat_cat, C, heads=8):
     x_c = F.linear(F.gelu(F.linear(y, w["mlp_c1.0.weight"], w["mlp_c1.0.bias"])), w["mlp_c1.2.weight"], w["mlp_c1.2.bias"]) + x_c
     o_p = F.conv2d(o_p, w["mlp_p0.weight"], w["mlp_p0.bias"], padding=1)
     o_p = F.interpolate(o_p, size=(hd, wd), mode="bilinear", align_corners=False)
-    x_p = kv + o_p
+    x_p = kv + drop_path_apply(o_p, dp[0])
     y = _gn1(x_p, w["norm_p1.weight"], w["norm_p1.bias"], 1e-6)
-    x_p = F.conv2d(F.gelu(F.conv2d(y, w["mlp_p1.0.weight"], w["mlp_p1.0.bias"])), w["mlp_p1.2.weight"], w["mlp_p1.2.bias"]) + x_p
+    x_p = drop_path_apply(F.conv2d(F.gelu(F.conv2d(y, w["mlp_p1.0.weight"], w["mlp_p1.0.bias"])), w["mlp_p1.2.weight"], w["mlp_p1.2.bias"]), dp[1]) + x_p
     return x_c, x_p
 
 
-def mctformer_lfca(sd, img, feat_diff, n_layers=12):
+def mctformer_lfca(sd, img, feat_diff, n_layers=12, dp=None):
     """MCTformerV2_DiG.forward(x, feat_diff=[5 x [B,1024,h,w]]) in eval mode: the extra dict entries of the LFCA
     branch, mctformer.py:265-291,324-346.  Returns {rcams, cam_diff, diff_cls, diff_pcls}."""
     col = {}
-    rcams = mctformer_cam(sd, img, n_layers, collect=col)
+    dp = dp or {}
+    rcams = mctformer_cam(sd, img, n_layers, collect=col, dp=dp.get("blocks"))
     B = img.shape[0]
     C = sd["cls_token"].shape[1]
     hd, wd = feat_diff[0].shape[2:]
     cat = torch.stack(feat_diff, dim=1).reshape(B, -1, hd, wd)  # timestep-major channel order (:275)
-    c0, p0 = lfca(_sub(sd, "LFCA0."), col["query0"], cat, C)
-    c1, p1 = lfca(_sub(sd, "LFCA1."), col["query1"], cat, C)
+    c0, p0 = lfca(_sub(sd, "LFCA0."), col["query0"], cat, C, dp=dp.get("LFCA0", (None, None)))
+    c1, p1 = lfca(_sub(sd, "LFCA1."), col["query1"], cat, C, dp=dp.get("LFCA1", (None, None)))
     out_c, out_p = (c0 + c1) / 2, (p0 + p1) / 2
     y = F.relu(F.conv2d(out_p, sd["diff_head_p.0.weight"], sd["diff_head_p.0.bias"], padding=1))
     cam_diff = F.conv2d(y, sd["diff_head_p.2.weight"], sd["diff_head_p.2.bias"])
@@ -453,17 +463,19 @@ def mctformer_lfca(sd, img, feat_diff, n_layers=12):
             "diff_pcls": top(F.relu(cam_diff)) - top(F.relu(-cam_diff))}
 
 
-def mctformer_outputs(sd, img, feat_diff=None, n_layers=12):
+def mctformer_outputs(sd, img, feat_diff=None, n_layers=12, dp=None):
     """The entries of MCTformerV2_DiG.forward's output dict that model_WSSS.update consumes (mctformer.py:293-346,
-    model.py:324-335): cls, pcls, cams (= relu(head)), mtatt, rcams and, with feat_diff, cam_diff / diff_cls / diff_pcls."""
+    model.py:324-335): cls, pcls, cams (= relu(head)), mtatt, rcams and, with feat_diff, cam_diff / diff_cls / diff_pcls.
+    dp: train-mode DropPath factors of this pass {"blocks": [(s_attn, s_mlp)] * depth, "LFCA0": (s, s), "LFCA1": (s, s)}."""
     col = {}
     B = img.shape[0]
     C = sd["cls_token"].shape[1]
+    dp = dp or {}
     if feat_diff is not None:
-        out = mctformer_lfca(sd, img, feat_diff, n_layers)
-        mctformer_cam(sd, img, n_layers, collect=col)
+        out = mctformer_lfca(sd, img, feat_diff, n_layers, dp=dp)
+        mctformer_cam(sd, img, n_layers, collect=col, dp=dp.get("blocks"))
     else:
-        out = {"rcams": mctformer_cam(sd, img, n_layers, collect=col)}
+        out = {"rcams": mctformer_cam(sd, img, n_layers, collect=col, dp=dp.get("blocks"))}
     head = col["head"]
     top = lambda t: torch.topk(t.reshape(B, C, -1), dim=-1, k=3)[0].mean(-1)
     out.update(cls=col["tokens"][:, :C].mean(-1), pcls=top(F.relu(head)) - top(F.relu(-head)), cams=col["fmap"], mtatt=col["mtatt"])
@@ -520,15 +532,15 @@ def mct_consistency_loss_grads(sd, img, img_diff, cam_diff, label, W=(1.0, 0.0, 
     return float(loss.detach()), {k: g for k, g in zip(names, grads) if g is not None}
 
 
-def mct_update_loss_grads(sd, img, feat_diff, img_diff, label, W=(1.0, 1.0, 1.0, 1.0, 10.0), T=5.0, A=0.2, epo=10):
+def mct_update_loss_grads(sd, img, feat_diff, img_diff, label, W=(1.0, 1.0, 1.0, 1.0, 10.0), T=5.0, A=0.2, epo=10, drop_path=None):
     """loss_trm.backward() of model_WSSS.update (model.py:322-424) with ALL five terms, by autograd over this file's forward
     restatement: first pass with the LFCA branch (its ViT queries detached, mctformer.py:280-281; teachers and cam_diff detached,
     model.py:349-350,389), second pass on img_diff.  sd must hold the LFCA0 / LFCA1 / diff_head_p parameters.
     -> (loss_trm, {state_dict key: gradient})."""
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
     with torch.enable_grad():
-        o1 = mctformer_outputs(leaves, img, feat_diff)
-        o2 = mctformer_outputs(leaves, img_diff)
+        o1 = mctformer_outputs(leaves, img, feat_diff, dp=(drop_path or {}).get("pass1"))  # drop_path: {"pass1": .., "pass2": ..}
+        o2 = mctformer_outputs(leaves, img_diff, dp=(drop_path or {}).get("pass2"))         # (net_trm.train(), model.py:320)
         loss = _update_loss_tensor(o1, o2, label, W, T, A, epo)
         names = [k for k in leaves]
         grads = torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)

@@ -416,6 +416,73 @@ def case_grads_update(mct, name, C, H, W, B, hd, wd, Wt=(1.0, 1.0, 1.0, 1.0, 10.
     save(name, **arrays)
 
 
+def case_grads_update_droppath(mct, name, C, H, W, B, hd, wd, Wt=(1.0, 1.0, 1.0, 1.0, 10.0), T=5.0, A=0.2, rate=0.3, seed=77):
+    """(f)-4 in TRAIN mode (model.py:320 net_trm.train()): as case_grads_update, with stochastic depth active in every ViT block
+    (vision_transformer.py:186,193-194, rates linspace(0, rate, 12)) and in both LFCAs (DropPath(0.1), mctformer.py:93,163-164).
+    timm is absent here: ref_import's DropPath stand-in multiplies by per-sample factors queued by this function (Bernoulli
+    draws from a seeded torch generator; rate 0.3 and B = 4 so that several samples are actually dropped), the reference's own
+    forward / autograd does the rest.  The factors are stored in the fixture: the product gets the same ones."""
+    m = mct.deit_small_MCTformerV2_DiG(num_classes=C, drop_path_rate=rate)
+    synth.fill_state_dict(m, seed=0, skip_prefixes=("norm.",))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.train()
+    img = synth.synth_imagenet_images(B, H, W, seed=6400)
+    img_diff = synth.synth_imagenet_images(B, H, W, seed=6401)
+    label = synth.synth_labels(B, C, seed=16)
+    feat = [synth.normal("feat_diff", (B, 1024, hd, wd), seed=47 + j) * 1.5 for j in range(5)]
+    g = torch.Generator().manual_seed(seed)
+    depth = len(m.blocks)
+    rates = [float(r) for r in torch.linspace(0, rate, depth)]
+
+    def draw(r):
+        keep = 1.0 - r
+        return (torch.rand(B, generator=g) < keep).float() / keep
+
+    dp = {}
+    for ps in ("pass1", "pass2"):
+        dp[ps] = {"blocks": [(draw(r), draw(r)) if r > 0 else (None, None) for r in rates]}
+    dp["pass1"]["LFCA0"] = (draw(0.1), draw(0.1))
+    dp["pass1"]["LFCA1"] = (draw(0.1), draw(0.1))
+    dp["pass1"]["LFCA1"] = (torch.tensor([0.0] + [1.0 / 0.9] * (B - 1)), dp["pass1"]["LFCA1"][1])  # make sure one LFCA branch IS dropped
+
+    def queue(ps):
+        for blk, f in zip(m.blocks, dp[ps]["blocks"]):
+            if f[0] is not None:
+                blk.drop_path.factors = [f[0], f[1]]
+        if ps == "pass1":
+            m.LFCA0.drop_path.factors = list(dp[ps]["LFCA0"])
+            m.LFCA1.drop_path.factors = list(dp[ps]["LFCA1"])
+
+    with torch.enable_grad():
+        for p in m.parameters():
+            p.requires_grad_(True)
+        queue("pass1")
+        o1 = m(img, feat_diff=feat)
+        queue("pass2")
+        o2 = m(img_diff)
+        loss = O._update_loss_tensor(o1, o2, label, Wt, T, A, 10)
+        loss.backward()
+    ref = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    lo, og = O.mct_update_loss_grads(sd, img, feat, img_diff, label, Wt, T, A, 10, drop_path=dp)
+    assert set(og) == set(ref), sorted(set(og) ^ set(ref))
+    rel = max(float((og[k] - ref[k]).norm() / (ref[k].norm() + 1e-30)) for k in ref)
+    ones = torch.ones(B)
+    fl = lambda f: torch.stack([ones if t is None else t for t in f])
+    arrays = {"label": label, "loss": np.float64(float(loss)), "W": np.array(Wt, np.float64), "T": np.float64(T), "A": np.float64(A),
+              "rate": np.float64(rate), "dp_pass1": torch.stack([fl(f) for f in dp["pass1"]["blocks"]]),
+              "dp_pass2": torch.stack([fl(f) for f in dp["pass2"]["blocks"]]),
+              "dp_lfca": torch.stack([fl(dp["pass1"]["LFCA0"]), fl(dp["pass1"]["LFCA1"])])}
+    names = sorted(ref)
+    arrays["names"] = np.array(names)
+    for i, k in enumerate(names):
+        idx = synth.sample_index(k, ref[k].numel())
+        arrays[f"g{i}_norm"] = np.float64(float(ref[k].double().norm()))
+        arrays[f"g{i}_sum"] = np.float64(float(ref[k].double().sum()))
+        arrays[f"g{i}_s"] = ref[k].flatten()[idx]
+    record(name, loss=abs(lo - float(loss)), grad_rel=rel)
+    save(name, **arrays)
+
+
 def synth_eval_set(C=20, seed=5):
     """Small synthetic CAM dicts + ground-truth maps (with 255 boundary pixels) for the evaluation cases."""
     rng = np.random.RandomState(seed)
@@ -551,6 +618,11 @@ def main():
         case_grads(mct, "grads224_c20", 20, 224, 224, 2)
         case_grads_consistency(mct, "grads_consistency224_c20", 20, 224, 224, 2, 14, 14)
         case_grads_update(mct, "grads_update224_c20", 20, 224, 224, 2, 14, 14)
+        case_grads_update_droppath(mct, "grads_update_droppath224_c20", 20, 224, 224, 4, 14, 14)
+        _merge_manifest()
+        return
+    if sys.argv[1:] == ["droppath"]:  # (f)-4 in train mode: stochastic depth with the draws given
+        case_grads_update_droppath(mct, "grads_update_droppath224_c20", 20, 224, 224, 4, 14, 14)
         _merge_manifest()
         return
     if sys.argv[1:] == ["eval"]:
@@ -572,6 +644,7 @@ def main():
     case_grads(mct, "grads224_c20", 20, 224, 224, 2)
     case_grads_consistency(mct, "grads_consistency224_c20", 20, 224, 224, 2, 14, 14)
     case_grads_update(mct, "grads_update224_c20", 20, 224, 224, 2, 14, 14)
+    case_grads_update_droppath(mct, "grads_update_droppath224_c20", 20, 224, 224, 4, 14, 14)
     case_lfca(mct, "lfca224_c20", 20, 224, 224, 14, 14)
     case_lfca(mct, "lfca224_c20_maps16", 20, 224, 224, 16, 16)  # guidance maps from a 256x256 diffusion input: bilinear 14 -> 16
     case_eval(ref_import.load_evaluation())

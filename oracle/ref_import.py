@@ -53,14 +53,24 @@ def _install_stubs():
     if "cv2" not in sys.modules:
         _stub("cv2", CAP_MSMF=0)
     if "timm" not in sys.modules:
-        class DropPath(nn.Module):  # identity in eval mode; the hot path is eval-only
+        class DropPath(nn.Module):
+            """Stand-in for timm.models.layers.DropPath (timm is absent from this image).  Identity in eval mode and at rate 0,
+            as timm's.  In train mode it multiplies by per-sample factors the CALLER queued in .factors (each a [B] tensor of
+            mask_b / keep_prob, timm's scale_by_keep form): the Bernoulli draw is not made here, so a fixture can hand the
+            very same factors to the product - what the fixture pins is the reference's own block arithmetic around the
+            call (vision_transformer.py:193-194, mctformer.py:163-164), not timm's random stream."""
+
             def __init__(self, p=0.0):
                 super().__init__()
                 self.p = p
+                self.factors = []
 
             def forward(self, x):
-                assert not self.training or self.p == 0.0, "stub DropPath is eval-only"
-                return x
+                if not self.training or self.p == 0.0:
+                    return x
+                assert self.factors, "stub DropPath in train mode: queue the per-sample factors first"
+                s = self.factors.pop(0)
+                return x * s.view(-1, *([1] * (x.dim() - 1)))
 
         def to_2tuple(x):
             return tuple(x) if isinstance(x, (tuple, list)) else (x, x)

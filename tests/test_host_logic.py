@@ -75,6 +75,29 @@ def test_adamw_rule_and_decay_filter():
     assert "blocks.0.attn.qkv.weight" not in nd and "head.weight" not in nd and "patch_embed.proj.weight" not in nd
 
 
+def test_draw_drop_path_follows_the_reference_rates():
+    """train.draw_drop_path: block i draws at linspace(0, drop_path_rate, depth)[i] (vision_transformer.py:265; block 0 has
+    rate 0 = nn.Identity = no factors), two draws per block (:193-194), two per LFCA at 0.1 in the first pass only
+    (mctformer.py:93,163-164); every factor is 0 or 1 / keep_prob (timm's scale_by_keep)."""
+    from dig_amd import train
+    m = create_model("deit_small_MCTformerV2_DiG", pretrained=False, num_classes=20, drop_path_rate=0.1, lfca=True)
+    g = torch.Generator().manual_seed(3)
+    dp = train.draw_drop_path(m, 64, "cpu", generator=g)
+    assert set(dp) == {"pass1", "pass2"} and set(dp["pass1"]) == {"blocks", "LFCA0", "LFCA1"} and set(dp["pass2"]) == {"blocks"}
+    rates = [float(r) for r in torch.linspace(0, 0.1, 12)]
+    for ps in ("pass1", "pass2"):
+        assert len(dp[ps]["blocks"]) == 12 and dp[ps]["blocks"][0] == (None, None)
+        for r, (a, b) in list(zip(rates, dp[ps]["blocks"]))[1:]:
+            for s_ in (a, b):
+                assert s_.shape == (64,) and set(s_.tolist()) <= {0.0, float(torch.tensor(1.0) / (1.0 - r))}
+    drops = sum(int((s_ == 0).sum()) for a, b in dp["pass1"]["blocks"][1:] for s_ in (a, b))
+    assert 20 <= drops <= 140  # expectation 64 * 2 * sum(rates) = 70
+    for k in ("LFCA0", "LFCA1"):
+        assert all(set(s_.tolist()) <= {0.0, float(torch.tensor(1.0) / 0.9)} for s_ in dp["pass1"][k])
+    m0 = create_model("deit_small_MCTformerV2_DiG", pretrained=False, num_classes=20, drop_path_rate=0.0, lfca=False)
+    assert train.draw_drop_path(m0, 4, "cpu", lfca=False) is None
+
+
 def test_state_dict_keys_and_no_cpu_fallback():
     u = Unet(dim=64, dim_mults=(1, 2, 4, 8), flash_attn=True)
     gd = GaussianDiffusion(u, image_size=224, timesteps=1000, sampling_timesteps=150).eval()
