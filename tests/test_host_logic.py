@@ -131,7 +131,7 @@ def test_mctformer_state_dict_matches_reference_call_site(C):
     m.load_state_dict({k: torch.zeros(v) for k, v in ref.items()}, strict=True)
     with pytest.raises(RuntimeError, match="HIP device only"):
         m.eval()(torch.zeros(1, 3, 224, 224), return_att=True)
-    with pytest.raises(NotImplementedError, match="forward-only"):
+    with pytest.raises(NotImplementedError, match="inference path"):
         m.train()(torch.zeros(1, 3, 224, 224))  # the reference's update() runs DropPath 0.1 here: refuse instead of diverging silently
     small = create_model("deit_small_MCTformerV2_DiG", pretrained=False, num_classes=C, lfca=False)  # explicit CAM-only opt-out
     assert set(small.state_dict()) == {k for k in ref if not k.startswith(("LFCA", "diff_head_p"))}
