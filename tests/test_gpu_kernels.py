@@ -300,6 +300,20 @@ def test_rmsnorm(dt, C):
     assert (nchw(y) - ref).abs().max() <= tol(dt, ref)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,H,W,h,w", [(64, 32, 32, 16, 16), (512, 32, 32, 16, 16), (100, 40, 24, 23, 31), (72, 9, 7, 16, 16), (64, 256, 256, 16, 16)])
+def test_bilinear_ac_tiled(dt, C, H, W, h, w):
+    """dig_bilinear_ac_concat (the LDS-transposed kernel: 64-channel x 128-pixel tiles, channel and pixel tails, several pixel
+    chunks per map) against F.interpolate(mode='bilinear', align_corners=True) of the same stored values (ddp.py:418,434);
+    the channels of the concat buffer outside the slice stay untouched."""
+    x = rnd("bil", (3, C, H, W)).to(dt).float()
+    buf = torch.full((3, C + 24, h, w), 7.0, device=DEV)
+    ops.bilinear_ac_into(nhwc(x, dt), buf, 16)
+    ref = F.interpolate(x, size=(h, w), mode="bilinear", align_corners=True)
+    assert (buf[:, 16:16 + C].cpu() - ref).abs().max() <= 1e-5 * max(1.0, float(ref.abs().max()))
+    assert torch.all(buf[:, :16] == 7.0) and torch.all(buf[:, 16 + C:] == 7.0)
+
+
 def test_small_kernels():
     # sinusoid (ddp.py:118-130)
     t = torch.tensor([0, 1, 4, 100, 999])
