@@ -19,6 +19,8 @@ Data flow of one Unet forward (activations NHWC, bf16 or fp32 storage, fp32 accu
 """
 import math
 
+import os
+
 import torch
 from torch import nn
 
@@ -289,13 +291,24 @@ def _pack_unet(u, dt):
 # --------------------------------------------------------------------------------------------------
 # forward building blocks (all on the current HIP stream)
 # --------------------------------------------------------------------------------------------------
+# Block2's GroupNorm + SiLU on its input (ddp.py:159-166): applied by the conv kernel's prologue as the halo is staged, or - for maps of
+# at most this many elements per image (the 32x32 levels: 256 and 512 channels) - by one in-place elementwise pass before a
+# plain conv.  The prologue costs a wide layer 22 us (every N-tile block transforms the same halo), the pass 13 us there; on
+# larger maps the pass costs more than the prologue (measured A/B at B = 32: 9.93 ms with 524288, 9.99 without, 9.97 with
+# 1048576, 10.05 with 2097152).  A function of the per-image shape only, never of the batch: results do not depend on B.
+_GN_INPLACE_MAX = int(os.environ.get("DIG_GN_INPLACE_MAX", "524288"))
+
+
 def _resnet(p, x0, x1, ss_all, debug=None, final=None):
     """ResnetBlock (ddp.py:169-194); x1 = second half of a fused channel concat (or None).
     final = (fw, fb, pred): fuse the Unet's final_conv into the block tail (ops.res_tail); returns None then."""
     hw = x0.shape[1] * x0.shape[2]
     c1, st1 = ops.conv3x3(x0, p["w1"], x1=x1)
     aff1 = ops.gn_finalize(st1, p["g1"], p["be1"], hw, ss=ss_all, ss_off=p["ss_off"], eps=p["eps"])
-    c2, st2 = ops.conv3x3(c1, p["w2"], aff=aff1)
+    if _GN_INPLACE_MAX and c1.shape[1] * c1.shape[2] * c1.shape[3] <= _GN_INPLACE_MAX:
+        c2, st2 = ops.conv3x3(ops.gn_silu_add(c1, aff1, inplace=True), p["w2"])
+    else:
+        c2, st2 = ops.conv3x3(c1, p["w2"], aff=aff1)
     aff2 = ops.gn_finalize(st2, p["g2"], p["be2"], hw, eps=p["eps"])
     if p["res"] is None:
         assert x1 is None

@@ -102,9 +102,9 @@ def gn_finalize(stats, gamma, beta, hw, ss=None, ss_off=0, eps=1e-5):
     return aff
 
 
-def gn_silu_add(x, aff, res=None):
+def gn_silu_add(x, aff, res=None, inplace=False):
     B, H, W, C = x.shape
-    out = torch.empty_like(x)
+    out = x if inplace else torch.empty_like(x)  # elementwise: out may alias x
     call("gn_silu_add", x=_chk(x), aff=aff, res=_chk(res) if res is not None else None, out=out, B=B, HW=H * W, C=C,
          dtype=dtype_code(x.dtype))
     return out
