@@ -8,13 +8,14 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // GroupNorm finalize: one 64-thread block per (image, group).  Partials are summed in a fixed order in
 // fp64 so the result is deterministic and free of E[x^2]-mean^2 cancellation at fp32.
-__global__ void gn_finalize_kernel(dig_gn_finalize_args a) {
-    const int b = blockIdx.x / a.groups, g = blockIdx.x % a.groups;
+// One wave finalizes group g of image b; dst receives (a, b) pairs at dst[2 * c] for the channels c of the group (c counted
+// from 0 of the image: the separate launch points dst at the image's row of the table, the fused kernel at its LDS copy).
+__device__ __forceinline__ void gn_finalize_group(const dig_gn_finalize_args& a, int b, int g, int lane, float* dst) {
     const int cpg = a.C / a.groups;
     const float* st = a.stats + ((size_t)b * a.groups + g) * a.tiles * 2;
     // the first channel's parameters are fetched beside the partials, not after the reduction (the kernel is one chain of
     // dependent L2 round trips: partials -> sums -> parameters -> store)
-    const int c0 = g * cpg + min((int)threadIdx.x, cpg - 1);
+    const int c0 = g * cpg + min(lane, cpg - 1);
     const float ga0 = a.gamma[c0], be0 = a.beta[c0];
     float sc0 = 1.0f, sh0 = 0.0f;
     if (a.ss) {
@@ -25,7 +26,7 @@ __global__ void gn_finalize_kernel(dig_gn_finalize_args a) {
     double s = 0.0, ss = 0.0;
     // 8 partials per round trip (all loads issued before the first add; the adds keep their order, so the sums are the same
     // bits as the plain loop's): at 256x256 the weight-stationary kernel leaves 1024 partials per (image, group)
-    for (int i0 = threadIdx.x; i0 < a.tiles; i0 += 64 * 8) {
+    for (int i0 = lane; i0 < a.tiles; i0 += 64 * 8) {
         f32x2 v[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -51,9 +52,9 @@ __global__ void gn_finalize_kernel(dig_gn_finalize_args a) {
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
     const float meanf = (float)mean;
-    for (int i = threadIdx.x; i < cpg; i += 64) {
+    for (int i = lane; i < cpg; i += 64) {
         const int c = g * cpg + i;
-        const bool first = i == (int)threadIdx.x;
+        const bool first = i == lane;
         float ga = (first ? ga0 : a.gamma[c]) * rstd;
         float be = (first ? be0 : a.beta[c]) - meanf * ga;
         if (a.ss) {
@@ -62,9 +63,47 @@ __global__ void gn_finalize_kernel(dig_gn_finalize_args a) {
             ga *= sc;
             be = be * sc + sh;
         }
-        float* d = a.aff + ((size_t)b * a.C + c) * 2;
-        d[0] = ga;
-        d[1] = be;
+        dst[2 * c] = ga;
+        dst[2 * c + 1] = be;
+    }
+}
+
+__global__ void gn_finalize_kernel(dig_gn_finalize_args a) {
+    const int b = blockIdx.x / a.groups, g = blockIdx.x % a.groups;
+    gn_finalize_group(a, b, g, threadIdx.x, a.aff + (size_t)b * a.C * 2);
+}
+
+// finalize + apply in one launch: block = (image, chunk of its HW * C / 8 vectors).  The four waves finalize the image's groups
+// into LDS (gn_finalize_group: the table's bits are those of the separate launch), then the block streams its chunk.
+constexpr int GN_FIN_MAXC = 1024, GN_FIN_MAX_TILES = 64;
+template <typename T> __global__ __launch_bounds__(256) void gn_fin_silu_add_kernel(dig_gn_fin_silu_add_args a, int chunks) {
+    __shared__ float saff[2 * GN_FIN_MAXC];
+    const int b = blockIdx.x / chunks, ch = blockIdx.x - b * chunks;
+    dig_gn_finalize_args fa;
+    fa.stats = a.stats; fa.gamma = a.gamma; fa.beta = a.beta; fa.ss = a.ss; fa.aff = nullptr;
+    fa.B = a.B; fa.C = a.C; fa.groups = a.groups; fa.tiles = a.tiles; fa.hw = a.hw; fa.ss_ld = a.ss_ld; fa.ss_off = a.ss_off; fa.eps = a.eps;
+    for (int g = threadIdx.x >> 6; g < a.groups; g += 4) gn_finalize_group(fa, b, g, threadIdx.x & 63, saff);
+    __syncthreads();
+    const int cv = a.C / 8;
+    const size_t per_img = (size_t)a.HW * cv;
+    const size_t per = (per_img + chunks - 1) / chunks;
+    const size_t v0 = (size_t)ch * per, v1 = v0 + per < per_img ? v0 + per : per_img;
+    const T* x = (const T*)a.x + (size_t)b * per_img * 8;
+    const T* res = a.res ? (const T*)a.res + (size_t)b * per_img * 8 : nullptr;
+    T* out = (T*)a.out + (size_t)b * per_img * 8;
+    for (size_t v = v0 + threadIdx.x; v < v1; v += 256) {
+        const int c = (int)(v % cv) * 8;
+        const float* af = saff + 2 * c;
+        Frag<T> f, r;
+        frag_load<T>(f, x + v * 8);
+        if (res) frag_load<T>(r, res + v * 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float y = silu_f(af[2 * j] * frag_get<T>(f, j) + af[2 * j + 1]);
+            if (res) y += frag_get<T>(r, j);
+            frag_set<T>(f, j, y);
+        }
+        frag_store<T>(f, out + v * 8);
     }
 }
 
@@ -484,6 +523,27 @@ extern "C" int dig_gn_finalize(const dig_gn_finalize_args* a, void* stream_) {
     DIG_CHECK(a->B > 0 && a->groups > 0 && a->C % a->groups == 0 && a->tiles > 0 && a->hw > 0, DIG_EINVAL, "gn_finalize: bad shape");
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(a->B * a->groups), dim3(64), 0, stream, *a);
     DIG_LAUNCH_CHECK("gn_finalize");
+    return DIG_OK;
+}
+
+extern "C" int dig_gn_fin_max_tiles(void) { return GN_FIN_MAX_TILES; }
+
+extern "C" int dig_gn_fin_silu_add(const dig_gn_fin_silu_add_args* a, void* stream_) {
+    STREAM;
+    DIG_CHECK(a && a->x && a->out && a->stats && a->gamma && a->beta, DIG_EINVAL, "gn_fin_silu_add: null pointer");
+    DIG_CHECK(a->C % 8 == 0 && a->C <= GN_FIN_MAXC && a->B > 0 && a->HW > 0 && a->hw > 0, DIG_EINVAL, "gn_fin_silu_add: bad shape B=%d HW=%d C=%d", a->B, a->HW, a->C);
+    DIG_CHECK(a->groups > 0 && a->C % a->groups == 0 && a->tiles > 0 && a->tiles <= GN_FIN_MAX_TILES, DIG_EINVAL,
+              "gn_fin_silu_add: groups=%d tiles=%d (at most %d partials per image and group: use dig_gn_finalize + dig_gn_silu_add)", a->groups, a->tiles, GN_FIN_MAX_TILES);
+    // chunks per image: about four blocks per CU over the batch, at least 2048 vectors (32 KB of bf16) per block
+    const long long per_img = (long long)a->HW * (a->C / 8);
+    long long chunks = (1024 + a->B - 1) / a->B;
+    if (chunks > per_img / 2048) chunks = per_img / 2048;
+    if (chunks < 1) chunks = 1;
+    DIG_CHECK((long long)a->B * chunks < (1ll << 31), DIG_EINVAL, "gn_fin_silu_add: too many blocks");
+    const dim3 grid((unsigned)(a->B * chunks));
+    if (a->dtype == DIG_BF16) hipLaunchKernelGGL(gn_fin_silu_add_kernel<bf16>, grid, dim3(256), 0, stream, *a, (int)chunks);
+    else hipLaunchKernelGGL(gn_fin_silu_add_kernel<float>, grid, dim3(256), 0, stream, *a, (int)chunks);
+    DIG_LAUNCH_CHECK("gn_fin_silu_add");
     return DIG_OK;
 }
 

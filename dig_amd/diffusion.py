@@ -297,6 +297,8 @@ def _pack_unet(u, dt):
 # larger maps the pass costs more than the prologue (measured A/B at B = 32: 9.93 ms with 524288, 9.99 without, 9.97 with
 # 1048576, 10.05 with 2097152).  A function of the per-image shape only, never of the batch: results do not depend on B.
 _GN_INPLACE_MAX = int(os.environ.get("DIG_GN_INPLACE_MAX", "524288"))
+# finalize inside the elementwise launch that consumes it where the statistics are few partials per image (ops.gn_fin_silu_add)
+_GN_FUSED_FIN = os.environ.get("DIG_GN_FUSED_FIN", "1") != "0"
 
 
 def _resnet(p, x0, x1, ss_all, debug=None, final=None):
@@ -304,15 +306,21 @@ def _resnet(p, x0, x1, ss_all, debug=None, final=None):
     final = (fw, fb, pred): fuse the Unet's final_conv into the block tail (ops.res_tail); returns None then."""
     hw = x0.shape[1] * x0.shape[2]
     c1, st1 = ops.conv3x3(x0, p["w1"], x1=x1)
-    aff1 = ops.gn_finalize(st1, p["g1"], p["be1"], hw, ss=ss_all, ss_off=p["ss_off"], eps=p["eps"])
     if _GN_INPLACE_MAX and c1.shape[1] * c1.shape[2] * c1.shape[3] <= _GN_INPLACE_MAX:
-        c2, st2 = ops.conv3x3(ops.gn_silu_add(c1, aff1, inplace=True), p["w2"])
+        if _GN_FUSED_FIN and ops.gn_fin_supported(st1, c1.shape[3]):
+            h1 = ops.gn_fin_silu_add(c1, st1, p["g1"], p["be1"], hw, ss=ss_all, ss_off=p["ss_off"], eps=p["eps"], inplace=True)
+        else:
+            h1 = ops.gn_silu_add(c1, ops.gn_finalize(st1, p["g1"], p["be1"], hw, ss=ss_all, ss_off=p["ss_off"], eps=p["eps"]), inplace=True)
+        c2, st2 = ops.conv3x3(h1, p["w2"])
     else:
+        aff1 = ops.gn_finalize(st1, p["g1"], p["be1"], hw, ss=ss_all, ss_off=p["ss_off"], eps=p["eps"])
         c2, st2 = ops.conv3x3(c1, p["w2"], aff=aff1)
-    aff2 = ops.gn_finalize(st2, p["g2"], p["be2"], hw, eps=p["eps"])
     if p["res"] is None:
         assert x1 is None
-        return ops.gn_silu_add(c2, aff2, res=x0)
+        if _GN_FUSED_FIN and ops.gn_fin_supported(st2, c2.shape[3]):
+            return ops.gn_fin_silu_add(c2, st2, p["g2"], p["be2"], hw, eps=p["eps"], res=x0)
+        return ops.gn_silu_add(c2, ops.gn_finalize(st2, p["g2"], p["be2"], hw, eps=p["eps"]), res=x0)
+    aff2 = ops.gn_finalize(st2, p["g2"], p["be2"], hw, eps=p["eps"])
     wr, br = p["res"]
     return ops.res_tail(x0, wr, br, x1, c2, aff2, hw, final=final)
 

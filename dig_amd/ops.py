@@ -110,6 +110,28 @@ def gn_silu_add(x, aff, res=None, inplace=False):
     return out
 
 
+_GN_FIN_MAX_TILES = None
+
+
+def gn_fin_supported(stats, C):
+    """whether gn_fin_silu_add takes these statistics (few partials per image and group, C <= 1024)"""
+    global _GN_FIN_MAX_TILES
+    if _GN_FIN_MAX_TILES is None:
+        _GN_FIN_MAX_TILES = int(_lib.lib().dig_gn_fin_max_tiles())
+    return stats.shape[2] <= _GN_FIN_MAX_TILES and C <= 1024
+
+
+def gn_fin_silu_add(x, stats, gamma, beta, hw, ss=None, ss_off=0, eps=1e-5, res=None, inplace=False):
+    """gn_finalize + gn_silu_add in one launch (stats [B,G,tiles,2] with tiles <= dig_gn_fin_max_tiles): out = silu(gn(x)) [+ res]"""
+    B, H, W, C = x.shape
+    _, G, tiles, _ = stats.shape
+    out = x if inplace else torch.empty_like(x)
+    call("gn_fin_silu_add", x=_chk(x), res=_chk(res) if res is not None else None, out=out, stats=stats, gamma=gamma, beta=beta, ss=ss,
+         B=B, HW=H * W, C=C, dtype=dtype_code(x.dtype), groups=G, tiles=tiles, hw=hw, ss_ld=ss.shape[1] if ss is not None else 0,
+         ss_off=ss_off, eps=eps)
+    return out
+
+
 def rmsnorm(x, g, res=None):
     C = x.shape[-1]
     out = torch.empty_like(x)

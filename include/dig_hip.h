@@ -119,6 +119,26 @@ typedef struct {
 } dig_gn_silu_add_args;
 int dig_gn_silu_add(const dig_gn_silu_add_args* a, void* stream);
 
+/* dig_gn_finalize + dig_gn_silu_add in ONE launch, for layers whose statistics are few partials per image (tiles <= 64): every
+ * block first reduces the partials of its image (the same arithmetic, in the same order, as dig_gn_finalize: the affine is
+ * bit-identical) into LDS, then applies out = silu(a*x + b) [+ res] to its slice of that image.  out may alias x.
+ * Replaces nn.GroupNorm + scale/shift + SiLU (+ the identity-shortcut add) of ddp.py:155-166,194 without the affine table's
+ * round trip through memory and without the 6 us launch that computed it. */
+typedef struct {
+    const void* x;
+    const void* res;
+    void* out;
+    const float* stats;
+    const float* gamma;
+    const float* beta;
+    const float* ss;
+    int B, HW, C, dtype, groups, tiles, hw, ss_ld, ss_off;
+    float eps;
+} dig_gn_fin_silu_add_args;
+int dig_gn_fin_silu_add(const dig_gn_fin_silu_add_args* a, void* stream);
+/* largest `tiles` dig_gn_fin_silu_add accepts (above it the per-block reduction costs more than the separate launch) */
+int dig_gn_fin_max_tiles(void);
+
 /* ResnetBlock tail with a channel-changing shortcut (ddp.py:190-194), streaming kernel for small K and N (the 256x256
  * and 128x128 levels):  out[m][:] = [x0 | x1][m][:] @ w^T + bias + SiLU(gaff.a * gsrc[m][:] + gaff.b).
  *   x0 [M][K0], x1 [M][K1] (or NULL), w [N][K0+K1], gsrc [M][N], gaff [M / rows_per_img][N][2], out [M][N].

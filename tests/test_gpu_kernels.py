@@ -314,6 +314,32 @@ def test_bilinear_ac_tiled(dt, C, H, W, h, w):
     assert torch.all(buf[:, :16] == 7.0) and torch.all(buf[:, 16 + C:] == 7.0)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C,G,tiles,with_ss,with_res", [(3, 32, 32, 512, 8, 4, True, False), (2, 64, 64, 128, 8, 16, False, True),
+                                                              (5, 9, 7, 72, 8, 1, True, True), (2, 128, 128, 64, 8, 64, False, True)])
+def test_gn_fin_silu_add_bitwise_equals_the_two_launches(dt, B, H, W, C, G, tiles, with_ss, with_res):
+    """dig_gn_fin_silu_add (GroupNorm finalize inside the elementwise launch, ddp.py:155-166,194) against dig_gn_finalize +
+    dig_gn_silu_add on the same partial statistics: BITWISE equal (the finalize arithmetic is one shared device function),
+    out of place and in place, with and without the time-embedding scale / shift and the residual; more than
+    dig_gn_fin_max_tiles partials per image are refused."""
+    x = nhwc(rnd("gfx", (B, C, H, W), 2.0), dt)
+    res = nhwc(rnd("gfr", (B, C, H, W)), dt) if with_res else None
+    st = (torch.rand(B, G, tiles, 2, generator=torch.Generator().manual_seed(5)) * 40 + 1).to(DEV)
+    st[..., 1] += 3000.0  # sum of squares well above (sum)^2 / n
+    gamma, beta = rnd("gfg", (C,)).to(DEV), rnd("gfb", (C,)).to(DEV)
+    ss = rnd("gfs", (B, 2 * C + 16)).to(DEV) if with_ss else None
+    aff = ops.gn_finalize(st, gamma, beta, H * W, ss=ss, ss_off=16 if with_ss else 0, eps=1e-5)
+    ref = ops.gn_silu_add(x, aff, res=res)
+    got = ops.gn_fin_silu_add(x, st, gamma, beta, H * W, ss=ss, ss_off=16 if with_ss else 0, eps=1e-5, res=res)
+    assert torch.equal(got, ref)
+    xi = x.clone()
+    assert ops.gn_fin_silu_add(xi, st, gamma, beta, H * W, ss=ss, ss_off=16 if with_ss else 0, eps=1e-5, res=res, inplace=True) is xi
+    assert torch.equal(xi, ref)
+    assert ops.gn_fin_supported(st, C) and not ops.gn_fin_supported(torch.empty(B, G, 65, 2), C)
+    with pytest.raises(RuntimeError, match="tiles"):
+        ops.gn_fin_silu_add(x, torch.ones(B, G, 65, 2, device=DEV), gamma, beta, H * W)
+
+
 def test_small_kernels():
     # sinusoid (ddp.py:118-130)
     t = torch.tensor([0, 1, 4, 100, 999])
