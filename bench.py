@@ -220,14 +220,12 @@ def main():
         ach = fl / sec / 1e12
         # HBM bytes per launch of this kernel class from the committed PMC passes (tools/pmc_traffic.py; bf16, B=32, 256x256 only)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-        if not os.path.exists(tpath):
-            tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath) and dt == torch.bfloat16 and B == 32 and S == 256:
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (3, 2, 1)) if os.path.exists(q)), None)  # the newest round's passes
+        if tpath and dt == torch.bfloat16 and B == 32 and S == 256:
             with open(tpath) as f:
                 traffic = json.load(f)["classes"].get(dom, {}).get("hbm_bytes_per_launch")
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes; " + (os.path.basename(tpath) if tpath else "none") + ")",
                 "algorithmic_bytes_per_launch_avg": round(by / n), "launches": n, "avg_launch_ms": round(1e3 * sec / n, 4),
                 "measured": f"HIP events on the launch stream around every conv3x3 launch, second pass of {args.steps} steps "
                             f"({1e3 * elapsed_instr / args.steps:.3f} ms/step with the event records in the stream)",
