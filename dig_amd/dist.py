@@ -59,7 +59,7 @@ def run_sharded(fn, *batched_inputs, group=None):
 
 
 class PipelinedGather:
-    """The all-gather of step i overlapped with the compute of step i+1: two output buffers, the collective is issued
+    """The all-gather of step i overlapped with the compute of step i+1: three output buffers in rotation, the collective is issued
     asynchronously (RCCL runs it on its own stream, behind the producing kernels of the current stream) and waited for
     one step later - a stream-level wait, the host never blocks.  `drain()` before reading the last result or stopping
     a timer.  With one rank it is the identity."""
@@ -68,19 +68,20 @@ class PipelinedGather:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.collective = self.world > 1 or (force and dist.is_initialized())  # force: run the collective even with one rank (rehearsal)
-        self.bufs = [torch.empty((self.world * shape[0],) + tuple(shape[1:]), dtype=dtype, device=device) for _ in range(2)] if self.collective else None
+        self.bufs = [torch.empty((self.world * shape[0],) + tuple(shape[1:]), dtype=dtype, device=device) for _ in range(3)] if self.collective else None
         self.pending = None  # (work, output buffer, input kept alive)
         self.count = 0
 
     def submit(self, local):
         """Queue the gather of `local` ([b, ...], equal b on every rank); returns the PREVIOUS step's gathered tensor (or None).
-        The returned tensor is one of the two internal buffers: it stays valid until the submit() AFTER the next one
-        overwrites it (two steps) - consume it within that window or .clone() it."""
+        The returned tensor is one of the three internal buffers: the next submit() leaves it alone (its collective writes the
+        third buffer), the one after that gathers into it - consume it within those two steps or .clone() it.  (With two
+        buffers the very next submit's collective would already write into the tensor just handed out.)"""
         if not self.collective:
             prev, self.pending = (self.pending[1] if self.pending else None), (None, local, None)
             return prev
         prev = self.drain()
-        out = self.bufs[self.count & 1]
+        out = self.bufs[self.count % 3]
         self.count += 1
         local = local.contiguous()
         work = dist.all_gather_into_tensor(out, local, group=self.group, async_op=True)

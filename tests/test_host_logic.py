@@ -245,6 +245,20 @@ assert pg.drain() is None and len(got) == 5
 for i, g in enumerate(got):
     want = torch.cat([torch.full((3, 4), float(10 * i + r)) for r in range(world)])
     assert torch.equal(g, want), (rank, i)
+# the buffer contract of submit(): the tensor it returns is one of three internal buffers - the NEXT submit leaves it alone,
+# the one after that gathers a new step into the same storage; a consumer that needs it longer clones it
+pg = dd.PipelinedGather((2,), torch.float32, "cpu")
+step = lambda i: torch.full((2,), float(100 * i + rank))
+whole = lambda i: torch.cat([torch.full((2,), float(100 * i + r)) for r in range(world)])
+assert pg.submit(step(0)) is None
+held = pg.submit(step(1))                  # result of step 0
+assert torch.equal(held, whole(0))
+nxt = pg.submit(step(2))                   # result of step 1; its own collective (step 2) goes to the third buffer
+pg.pending[0].wait()                       # let the step-2 gather finish: it must not have touched `held`
+assert torch.equal(held, whole(0)) and torch.equal(nxt, whole(1)) and nxt.data_ptr() != held.data_ptr()
+pg.submit(step(3))                         # this one gathers step 3 into the buffer `held` points at
+assert torch.equal(pg.drain(), whole(3))
+assert torch.equal(held, whole(3))         # overwritten two submits later, as documented
 dist.destroy_process_group()
 print("ok", rank)
 """
